@@ -1,0 +1,377 @@
+"""Thin Python glue over libhenjou_hip.so (C-ABI: include/henjou_hip.h).
+
+Python is plumbing here — tests, bench.py and the torch.distributed (RCCL) framebuffer exchange.  The product is
+the C++/HIP library; this module adds no compute path and no fallback: if the library is missing or no MI355X is
+present, the calls raise.
+
+`Renderer` mirrors the reference's `class Renderer` (renderer/renderer.h:900-1318): loadRenderOption,
+loadGLTFfile, build, and a per-frame render that returns the linear float4 AOVs.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+REPO_ROOT = os.path.dirname(PKG_DIR)
+LIB_PATH = os.path.join(PKG_DIR, "libhenjou_hip.so")
+ASSETS = os.path.join(PKG_DIR, "assets")
+
+INTEGRATOR_NEE, INTEGRATOR_PT, INTEGRATOR_MIS = 0, 1, 2
+FLAG_STATS, FLAG_ZERO_UNOWNED = 1, 2
+
+
+class HjrError(RuntimeError):
+    pass
+
+
+class Material(C.Structure):
+    _fields_ = [("basecolor", C.c_float * 3), ("metallic", C.c_float), ("roughness", C.c_float),
+                ("sheen", C.c_float), ("clearcoat", C.c_float), ("ior", C.c_float),
+                ("transmission", C.c_float), ("emission", C.c_float * 3), ("is_light", C.c_int32),
+                ("ideal_specular", C.c_int32), ("is_thinfilm", C.c_int32), ("basecolor_tex", C.c_int32)]
+
+
+MATERIAL_DTYPE = np.dtype([("basecolor", "<f4", 3), ("metallic", "<f4"), ("roughness", "<f4"), ("sheen", "<f4"),
+                           ("clearcoat", "<f4"), ("ior", "<f4"), ("transmission", "<f4"), ("emission", "<f4", 3),
+                           ("is_light", "<i4"), ("ideal_specular", "<i4"), ("is_thinfilm", "<i4"),
+                           ("basecolor_tex", "<i4")])
+
+
+class SceneView(C.Structure):
+    _fields_ = [("n_vertices", C.c_uint32), ("n_triangles", C.c_uint32), ("n_instances", C.c_uint32),
+                ("n_materials", C.c_uint32), ("n_lights", C.c_uint32), ("n_animations", C.c_uint32),
+                ("vertices", C.c_void_p), ("normals", C.c_void_p), ("texcoords", C.c_void_p),
+                ("indices", C.c_void_p), ("material_ids", C.c_void_p), ("prim_offset", C.c_void_p),
+                ("geometry_index_offset", C.c_void_p), ("geometry_index_count", C.c_void_p),
+                ("instance_animation_id", C.c_void_p), ("materials", C.c_void_p),
+                ("light_prim_ids", C.c_void_p), ("light_prim_emission", C.c_void_p)]
+
+
+class RenderOption(C.Structure):
+    _fields_ = [("image_width", C.c_uint32), ("image_height", C.c_uint32), ("image_name", C.c_char * 256),
+                ("image_directory", C.c_char * 512), ("max_spp", C.c_uint32), ("gltf_path", C.c_char * 512),
+                ("gltf_name", C.c_char * 256), ("fps", C.c_uint32), ("start_frame", C.c_uint32),
+                ("end_frame", C.c_uint32), ("time_limit", C.c_float), ("allow_camera_animation", C.c_int32),
+                ("camera_fov", C.c_float), ("camera_position", C.c_float * 3), ("camera_direction", C.c_float * 3),
+                ("camera_animation_id", C.c_int32), ("render_mode", C.c_int32), ("ptxfile_path", C.c_char * 512),
+                ("use_IBL", C.c_int32), ("IBL_path", C.c_char * 512), ("IBL_intensity", C.c_float),
+                ("scene_sky_default", C.c_float * 3), ("use_date", C.c_int32), ("save_renderOption", C.c_int32),
+                ("LUT_path", C.c_char * 512), ("seed", C.c_uint32), ("integrator", C.c_int32)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("pos", C.c_float * 3), ("dir", C.c_float * 3), ("up", C.c_float * 3), ("right", C.c_float * 3),
+                ("f", C.c_float)]
+
+    def as_dict(self):
+        return {"pos": list(self.pos), "dir": list(self.dir), "up": list(self.up), "right": list(self.right),
+                "f": float(self.f)}
+
+
+class Params(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("spp", C.c_uint32), ("frame", C.c_uint32),
+                ("seed", C.c_uint32), ("integrator", C.c_uint32), ("camera", Camera), ("sky", C.c_float * 3),
+                ("ibl_intensity", C.c_float), ("rank", C.c_uint32), ("world_size", C.c_uint32),
+                ("flags", C.c_uint32), ("_reserved", C.c_uint32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("samples", "closest_rays", "shadow_rays", "box_tests_closest",
+                                           "tri_tests_closest", "box_tests_shadow", "tri_tests_shadow",
+                                           "shaded_hits", "light_samples", "nan_samples")] + \
+               [("last_kernel_ms", C.c_float), ("bvh_nodes", C.c_uint32), ("bvh_depth", C.c_uint32),
+                ("n_triangles", C.c_uint32)]
+
+    def as_dict(self):
+        return {n: (float(getattr(self, n)) if n == "last_kernel_ms" else int(getattr(self, n)))
+                for n, _ in self._fields_}
+
+
+_lib = None
+
+
+def lib():
+    """Loads libhenjou_hip.so.  Raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HjrError("libhenjou_hip.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "or `make -C henjou-renderer_amd`; there is no fallback path")
+        L = C.CDLL(LIB_PATH)
+        L.hjr_last_error.restype = C.c_char_p
+        for name, args in {
+            "hjr_load_render_option": [C.c_char_p, C.c_void_p],
+            "hjr_scene_load_gltf": [C.c_char_p, C.c_char_p, C.c_void_p, C.c_void_p],
+            "hjr_scene_get_view": [C.c_void_p, C.c_void_p],
+            "hjr_scene_eval_transforms": [C.c_void_p, C.c_float, C.c_void_p, C.c_void_p],
+            "hjr_scene_eval_camera": [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p],
+            "hjr_load_png_rgba8": [C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p],
+            "hjr_create": [C.c_int, C.c_void_p],
+            "hjr_upload_scene": [C.c_void_p, C.c_void_p],
+            "hjr_set_transforms": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32],
+            "hjr_set_lut": [C.c_void_p, C.c_void_p, C.c_int, C.c_int],
+            "hjr_render": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
+            "hjr_render_device": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
+            "hjr_synchronize": [C.c_void_p],
+            "hjr_get_stats": [C.c_void_p, C.c_void_p],
+            "hjr_float4_to_srgb8": [C.c_void_p, C.c_void_p, C.c_uint32],
+            "hjr_write_png": [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int],
+            "hjr_write_pfm": [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32],
+            "hjr_render_file": [C.c_char_p, C.c_int],
+        }.items():
+            fn = getattr(L, name)
+            fn.restype = C.c_int
+            fn.argtypes = args
+        L.hjr_scene_free.argtypes = [C.c_void_p]
+        L.hjr_scene_free.restype = None
+        L.hjr_destroy.argtypes = [C.c_void_p]
+        L.hjr_destroy.restype = None
+        L.hjr_free.argtypes = [C.c_void_p]
+        L.hjr_free.restype = None
+        _lib = L
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise HjrError("%s failed (%d): %s" % (what, rc, lib().hjr_last_error().decode("utf-8", "replace")))
+
+
+def _np(ptr, count, dtype):
+    if not ptr or count == 0:
+        return np.zeros(0, dtype=dtype)
+    buf = (C.c_char * (count * np.dtype(dtype).itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype, count=count).copy()
+
+
+def load_render_option(path):
+    """load_json (loader/render_json_loader.h:78-228)."""
+    opt = RenderOption()
+    _check(lib().hjr_load_render_option(os.fsencode(path), C.byref(opt)), "hjr_load_render_option")
+    return opt
+
+
+def load_png(path):
+    p = C.c_void_p()
+    w, h = C.c_int(), C.c_int()
+    _check(lib().hjr_load_png_rgba8(os.fsencode(path), C.byref(p), C.byref(w), C.byref(h)), "hjr_load_png_rgba8")
+    a = _np(p.value, w.value * h.value * 4, np.uint8).reshape(h.value, w.value, 4)
+    lib().hjr_free(p)
+    return a
+
+
+def write_png(path, rgba8, flip_y=True):
+    a = np.ascontiguousarray(rgba8, dtype=np.uint8)
+    _check(lib().hjr_write_png(os.fsencode(path), a.ctypes.data, a.shape[1], a.shape[0], 1 if flip_y else 0), "hjr_write_png")
+
+
+def float4_to_srgb8(rgba):
+    a = np.ascontiguousarray(rgba, dtype=np.float32)
+    out = np.zeros(a.shape, dtype=np.uint8)
+    _check(lib().hjr_float4_to_srgb8(a.ctypes.data, out.ctypes.data, a.size // 4), "hjr_float4_to_srgb8")
+    return out
+
+
+class Scene:
+    """Owning handle of a loaded glTF scene (SceneData, renderer/scene.h:19-36)."""
+
+    def __init__(self, directory, filename, opt):
+        self._h = C.c_void_p()
+        _check(lib().hjr_scene_load_gltf(os.fsencode(directory), os.fsencode(filename), C.byref(opt), C.byref(self._h)),
+               "hjr_scene_load_gltf")
+        self.view = SceneView()
+        _check(lib().hjr_scene_get_view(self._h, C.byref(self.view)), "hjr_scene_get_view")
+
+    def close(self):
+        if self._h:
+            lib().hjr_scene_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def transforms(self, time):
+        n = self.view.n_instances
+        m = np.zeros((n, 12), dtype=np.float32)
+        inv = np.zeros((n, 12), dtype=np.float32)
+        _check(lib().hjr_scene_eval_transforms(self._h, C.c_float(time), m.ctypes.data, inv.ctypes.data),
+               "hjr_scene_eval_transforms")
+        return m, inv
+
+    def camera(self, opt, time):
+        cam = Camera()
+        _check(lib().hjr_scene_eval_camera(self._h, C.byref(opt), C.c_float(time), C.byref(cam)), "hjr_scene_eval_camera")
+        return cam
+
+    def arrays(self, time=None):
+        """numpy copies of the SceneData columns (+ transforms at `time`) — the oracle's input in tests/bench."""
+        v = self.view
+        a = {
+            "vertices": _np(v.vertices, v.n_vertices * 3, np.float32),
+            "normals": _np(v.normals, v.n_vertices * 3, np.float32),
+            "texcoords": _np(v.texcoords, v.n_vertices * 2, np.float32),
+            "indices": _np(v.indices, v.n_triangles * 3, np.uint32),
+            "material_ids": _np(v.material_ids, v.n_triangles, np.uint32),
+            "prim_offsets": _np(v.prim_offset, v.n_instances, np.uint32),
+            "geometry_index_offset": _np(v.geometry_index_offset, v.n_instances, np.uint32),
+            "geometry_index_count": _np(v.geometry_index_count, v.n_instances, np.uint32),
+            "instance_animation_id": _np(v.instance_animation_id, v.n_instances, np.uint32),
+            "materials": _np(v.materials, v.n_materials, MATERIAL_DTYPE),
+            "light_prim_ids": _np(v.light_prim_ids, v.n_lights, np.uint32),
+            "light_prim_emission": _np(v.light_prim_emission, v.n_lights * 3, np.float32),
+        }
+        if time is not None:
+            a["transforms"], a["inv_transforms"] = self.transforms(time)
+        return a
+
+
+class Device:
+    """One hjr_ctx (one per GPU / per process)."""
+
+    def __init__(self, ordinal=0):
+        self._h = C.c_void_p()
+        _check(lib().hjr_create(ordinal, C.byref(self._h)), "hjr_create")
+
+    def close(self):
+        if self._h:
+            lib().hjr_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload_scene(self, view):
+        _check(lib().hjr_upload_scene(self._h, C.byref(view)), "hjr_upload_scene")
+
+    def upload_arrays(self, a):
+        """Upload from numpy arrays (keys as Scene.arrays())."""
+        self._keep = {k: np.ascontiguousarray(a[k]) for k in ("vertices", "normals", "texcoords", "indices", "material_ids",
+                                                              "prim_offsets", "materials", "light_prim_ids", "light_prim_emission")}
+        k = self._keep
+        v = SceneView()
+        v.n_vertices = k["vertices"].size // 3
+        v.n_triangles = k["indices"].size // 3
+        v.n_instances = k["prim_offsets"].size
+        v.n_materials = k["materials"].size
+        v.n_lights = k["light_prim_ids"].size
+        for name, key in (("vertices", "vertices"), ("normals", "normals"), ("texcoords", "texcoords"), ("indices", "indices"),
+                          ("material_ids", "material_ids"), ("prim_offset", "prim_offsets"), ("materials", "materials"),
+                          ("light_prim_ids", "light_prim_ids"), ("light_prim_emission", "light_prim_emission")):
+            setattr(v, name, k[key].ctypes.data if k[key].size else None)
+        self.upload_scene(v)
+
+    def set_transforms(self, m, inv):
+        m = np.ascontiguousarray(m, dtype=np.float32)
+        inv = np.ascontiguousarray(inv, dtype=np.float32)
+        _check(lib().hjr_set_transforms(self._h, m.ctypes.data, inv.ctypes.data, m.size // 12), "hjr_set_transforms")
+
+    def set_lut(self, rgba):
+        if rgba is None:
+            _check(lib().hjr_set_lut(self._h, None, 0, 0), "hjr_set_lut")
+            return
+        a = np.ascontiguousarray(rgba, dtype=np.uint8)
+        _check(lib().hjr_set_lut(self._h, a.ctypes.data, a.shape[1], a.shape[0]), "hjr_set_lut")
+
+    def render(self, params, want_aovs=True):
+        """Synchronous render into host arrays (hjr_render)."""
+        shp = (params.height, params.width, 4)
+        color = np.zeros(shp, dtype=np.float32)
+        albedo = np.zeros(shp, dtype=np.float32) if want_aovs else None
+        normal = np.zeros(shp, dtype=np.float32) if want_aovs else None
+        _check(lib().hjr_render(self._h, C.byref(params), color.ctypes.data,
+                                albedo.ctypes.data if want_aovs else None, normal.ctypes.data if want_aovs else None), "hjr_render")
+        return color, albedo, normal
+
+    def render_device(self, params, d_color, d_albedo=None, d_normal=None, stream=None):
+        """Asynchronous render into device pointers (ints, e.g. torch tensor .data_ptr()) on a hipStream_t (int)."""
+        _check(lib().hjr_render_device(self._h, C.byref(params), C.c_void_p(d_color),
+                                       C.c_void_p(d_albedo) if d_albedo else None, C.c_void_p(d_normal) if d_normal else None,
+                                       C.c_void_p(stream) if stream else None), "hjr_render_device")
+
+    def synchronize(self):
+        _check(lib().hjr_synchronize(self._h), "hjr_synchronize")
+
+    def stats(self):
+        st = Stats()
+        _check(lib().hjr_get_stats(self._h, C.byref(st)), "hjr_get_stats")
+        return st.as_dict()
+
+
+def make_params(width, height, spp, camera, frame=1, seed=1, integrator=INTEGRATOR_NEE, sky=(0.8, 0.8, 0.8),
+                ibl_intensity=1.0, rank=0, world_size=1, flags=0):
+    p = Params()
+    p.width, p.height, p.spp, p.frame, p.seed, p.integrator = width, height, spp, frame, seed, integrator
+    if isinstance(camera, Camera):
+        p.camera = camera
+    else:
+        p.camera.pos = (C.c_float * 3)(*camera["pos"])
+        p.camera.dir = (C.c_float * 3)(*camera["dir"])
+        p.camera.up = (C.c_float * 3)(*camera["up"])
+        p.camera.right = (C.c_float * 3)(*camera["right"])
+        p.camera.f = camera["f"]
+    p.sky = (C.c_float * 3)(*sky)
+    p.ibl_intensity = ibl_intensity
+    p.rank, p.world_size, p.flags = rank, world_size, flags
+    return p
+
+
+def owned_tile_mask(width, height, rank, world_size, tile=8):
+    """Boolean [height, width] mask of the pixels rank `rank` renders (8x8 tiles dealt round-robin)."""
+    tx = (np.arange(width) // tile)[None, :]
+    ty = (np.arange(height) // tile)[:, None]
+    tiles_x = (width + tile - 1) // tile
+    return ((ty * tiles_x + tx) % world_size) == rank
+
+
+class Renderer:
+    """Mirror of the reference's `class Renderer` (renderer/renderer.h:900-1318) on top of the C-ABI."""
+
+    def __init__(self, device_ordinal=0):
+        self.device_ordinal = device_ordinal
+        self.render_option = None
+        self.scene = None
+        self.device = None
+
+    def loadRenderOption(self, path):  # renderer.h:1041-1051
+        self.render_option = load_render_option(path)
+        return True
+
+    def setRenderOption(self, opt):  # renderer.h:992-995
+        self.render_option = opt
+
+    def loadGLTFfile(self, filepath, filename):  # renderer.h:1005-1013
+        self.scene = Scene(filepath, filename, self.render_option)
+        return True
+
+    def build(self):  # renderer.h:1015-1039
+        self.device = Device(self.device_ordinal)
+        self.device.upload_scene(self.scene.view)
+        lut_path = self.render_option.LUT_path.decode()
+        if lut_path and os.path.exists(lut_path):
+            self.device.set_lut(load_png(lut_path))
+
+    def frame_params(self, frame, spp=None, rank=0, world_size=1, flags=0):
+        o = self.render_option
+        time = frame / float(o.fps)
+        cam = self.scene.camera(o, time)
+        return make_params(o.image_width, o.image_height, spp or o.max_spp, cam, frame=frame, seed=o.seed,
+                           integrator=o.integrator, sky=tuple(o.scene_sky_default), ibl_intensity=o.IBL_intensity,
+                           rank=rank, world_size=world_size, flags=flags), time
+
+    def render_frame(self, frame, spp=None):
+        """One iteration of the frame loop (renderer.h:1126-1245): IAS update, camera, launch; returns float4 AOVs."""
+        p, time = self.frame_params(frame, spp)
+        m, inv = self.scene.transforms(time)
+        self.device.set_transforms(m, inv)
+        return self.device.render(p)
+
+    def initializeAndRender(self, render_option_path):  # renderer.h:1053-1317
+        _check(lib().hjr_render_file(os.fsencode(render_option_path), self.device_ordinal), "hjr_render_file")
+        return True

@@ -1,0 +1,306 @@
+// Device context of libhenjou_hip.so: HBM-resident scene, per-frame BVH upload, kernel launch and timing.
+// Replaces the reference's CUDA/OptiX plumbing (renderer/renderer.h:197-255 upload, 293-739 context/GAS/IAS/pipeline/SBT,
+// 1175-1242 Params fill + optixLaunch).  No CPU fallback exists: without a gfx950 device every entry point fails loudly.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/henjou_hip.h"
+#include "../host/frame.hpp"
+#include "hjr_kernel.hip.h"
+
+namespace hjr {
+void set_error(const std::string& s);
+}
+using hjr::set_error;
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    bool upload(const void* src, size_t bytes, hipStream_t st)
+    {
+        if (bytes > cap) {
+            if (p) (void)hipFree(p);
+            p = nullptr; cap = 0;
+            size_t want = bytes + bytes / 4 + 256;
+            if (hipMalloc(&p, want) != hipSuccess) return false;
+            cap = want;
+        }
+        if (bytes && hipMemcpyAsync(p, src, bytes, hipMemcpyHostToDevice, st) != hipSuccess) return false;
+        return true;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct hjr_ctx {
+    int device = 0;
+    int n_cus = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hjr::SceneCopy scene;
+    bool have_scene = false, have_frame = false;
+    hjr::FrameData frame;
+    DevBuf d_nodes, d_tri_geom, d_tri_shade, d_tri_inst, d_materials, d_lights, d_lut, d_work;
+    int lut_w = 0, lut_h = 0;
+    DevBuf d_color, d_albedo, d_normal; // staging for hjr_render (host buffers)
+    hjr_stats stats;
+    bool event_pending = false;
+    int blocks_per_cu = 4;
+};
+
+#define HIPCHK(call)                                                                                            \
+    do {                                                                                                        \
+        hipError_t e_ = (call);                                                                                 \
+        if (e_ != hipSuccess) {                                                                                 \
+            set_error(std::string(#call) + " failed: " + hipGetErrorString(e_));                               \
+            return HJR_ERR_DEVICE;                                                                              \
+        }                                                                                                       \
+    } while (0)
+
+extern "C" int hjr_create(int device, hjr_ctx** out)
+{
+    if (!out) { set_error("hjr_create: null out pointer"); return HJR_ERR_ARG; }
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        set_error(std::string("hjr_create: no HIP device available (") + hipGetErrorString(e) + "); this library has no CPU fallback");
+        return HJR_ERR_DEVICE;
+    }
+    if (device < 0 || device >= n) { set_error("hjr_create: device ordinal out of range"); return HJR_ERR_ARG; }
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error(std::string("hjr_create: device is ") + prop.gcnArchName + ", this library carries gfx950 (MI355X) code objects only");
+        return HJR_ERR_DEVICE;
+    }
+    hjr_ctx* c = new hjr_ctx();
+    c->device = device;
+    c->n_cus = prop.multiProcessorCount;
+    memset(&c->stats, 0, sizeof(c->stats));
+    if (const char* b = getenv("HJR_BLOCKS_PER_CU")) { int v = atoi(b); if (v >= 1 && v <= 8) c->blocks_per_cu = v; }
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess ||
+        hipEventCreate(&c->ev1) != hipSuccess) {
+        set_error("hjr_create: stream/event creation failed");
+        delete c;
+        return HJR_ERR_DEVICE;
+    }
+    *out = c;
+    return HJR_OK;
+}
+
+extern "C" void hjr_destroy(hjr_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    for (DevBuf* b : { &c->d_nodes, &c->d_tri_geom, &c->d_tri_shade, &c->d_tri_inst, &c->d_materials, &c->d_lights, &c->d_lut,
+                       &c->d_work, &c->d_color, &c->d_albedo, &c->d_normal })
+        b->release();
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int hjr_upload_scene(hjr_ctx* c, const hjr_scene_view* v)
+{
+    if (!c || !v) { set_error("hjr_upload_scene: null argument"); return HJR_ERR_ARG; }
+    std::string err;
+    if (!c->scene.set(*v, err)) { set_error("hjr_upload_scene: " + err); return HJR_ERR_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    static_assert(sizeof(hjr_material) == 64, "hjr_material must be 4 x float4");
+    if (!c->d_materials.upload(c->scene.materials.data(), c->scene.materials.size() * sizeof(hjr_material), c->stream)) {
+        set_error("hjr_upload_scene: material upload failed");
+        return HJR_ERR_DEVICE;
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->have_scene = true;
+    c->have_frame = false;
+    return HJR_OK;
+}
+
+extern "C" int hjr_set_transforms(hjr_ctx* c, const float* m, const float* inv, uint32_t n)
+{
+    if (!c || (n && (!m || !inv))) { set_error("hjr_set_transforms: null argument"); return HJR_ERR_ARG; }
+    if (!c->have_scene) { set_error("hjr_set_transforms: no scene uploaded"); return HJR_ERR_STATE; }
+    std::string err;
+    if (!hjr::build_frame(c->scene, m, inv, n, c->frame, err)) { set_error("hjr_set_transforms: " + err); return HJR_ERR_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    const hjr::FrameData& f = c->frame;
+    bool ok = c->d_nodes.upload(f.nodes.data(), f.nodes.size() * 4, c->stream) &&
+              c->d_tri_geom.upload(f.tri_geom.data(), f.tri_geom.size() * 4, c->stream) &&
+              c->d_tri_shade.upload(f.tri_shade.data(), f.tri_shade.size() * 4, c->stream) &&
+              c->d_tri_inst.upload(f.tri_inst.data(), f.tri_inst.size() * 4, c->stream) &&
+              c->d_lights.upload(f.lights.data(), f.lights.size() * 4, c->stream);
+    if (!ok) { set_error("hjr_set_transforms: device upload failed"); return HJR_ERR_DEVICE; }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->have_frame = true;
+    c->stats.bvh_nodes = f.n_nodes;
+    c->stats.bvh_depth = f.depth;
+    c->stats.n_triangles = f.n_tris;
+    return HJR_OK;
+}
+
+extern "C" int hjr_set_lut(hjr_ctx* c, const uint8_t* rgba, int w, int h)
+{
+    if (!c) { set_error("hjr_set_lut: null context"); return HJR_ERR_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    if (!rgba || w <= 0 || h <= 0) { c->lut_w = c->lut_h = 0; return HJR_OK; }
+    if (!c->d_lut.upload(rgba, (size_t)w * (size_t)h * 4, c->stream)) { set_error("hjr_set_lut: upload failed"); return HJR_ERR_DEVICE; }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->lut_w = w; c->lut_h = h;
+    return HJR_OK;
+}
+
+template <int I, bool S> static void launch(const KParams& kp, dim3 grid, hipStream_t st)
+{
+    hipLaunchKernelGGL((hjr_render_kernel<I, S>), grid, dim3(HJR_BLOCK), 0, st, kp);
+}
+
+static int render_impl(hjr_ctx* c, const hjr_params* p, void* d_color, void* d_albedo, void* d_normal, hipStream_t st)
+{
+    if (!c || !p || !d_color) { set_error("hjr_render: null argument"); return HJR_ERR_ARG; }
+    if (!c->have_scene || !c->have_frame) { set_error("hjr_render: upload a scene and set transforms first"); return HJR_ERR_STATE; }
+    if (p->width == 0 || p->height == 0 || p->spp == 0) { set_error("hjr_render: width, height and spp must be positive"); return HJR_ERR_ARG; }
+    if (p->integrator > HJR_INTEGRATOR_MIS) { set_error("hjr_render: unknown integrator"); return HJR_ERR_ARG; }
+    const uint32_t world = p->world_size ? p->world_size : 1u;
+    if (p->rank >= world) { set_error("hjr_render: rank >= world_size"); return HJR_ERR_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+
+    const uint32_t tiles_x = (p->width + HJR_TILE - 1) / HJR_TILE, tiles_y = (p->height + HJR_TILE - 1) / HJR_TILE;
+    const uint64_t n_tiles = (uint64_t)tiles_x * tiles_y;
+    const uint64_t owned = (n_tiles > p->rank) ? (n_tiles - p->rank + world - 1) / world : 0;
+    if (owned * 64 >= 0xffffffffull) { set_error("hjr_render: image too large"); return HJR_ERR_ARG; }
+
+    // work area: [0] queue head, [16..] HJR_NSTAT uint64 counters
+    const size_t work_bytes = 16 + HJR_NSTAT * 8;
+    if (c->d_work.cap < work_bytes) {
+        std::vector<unsigned char> z(work_bytes, 0);
+        if (!c->d_work.upload(z.data(), work_bytes, st)) { set_error("hjr_render: work buffer allocation failed"); return HJR_ERR_DEVICE; }
+    }
+    HIPCHK(hipMemsetAsync(c->d_work.p, 0, work_bytes, st));
+    const size_t img_bytes = (size_t)p->width * p->height * 16;
+    if (world > 1 && (p->flags & HJR_FLAG_ZERO_UNOWNED)) {
+        HIPCHK(hipMemsetAsync(d_color, 0, img_bytes, st));
+        if (d_albedo) HIPCHK(hipMemsetAsync(d_albedo, 0, img_bytes, st));
+        if (d_normal) HIPCHK(hipMemsetAsync(d_normal, 0, img_bytes, st));
+    }
+
+    KParams kp;
+    memset(&kp, 0, sizeof(kp));
+    kp.nodes = (const float4*)c->d_nodes.p;
+    kp.tri_geom = (const float4*)c->d_tri_geom.p;
+    kp.tri_shade = (const float4*)c->d_tri_shade.p;
+    kp.tri_inst = (const uint32_t*)c->d_tri_inst.p;
+    kp.materials = (const float4*)c->d_materials.p;
+    kp.lights = (const float4*)c->d_lights.p;
+    kp.lut = (c->lut_w > 0) ? (const uchar4*)c->d_lut.p : nullptr;
+    kp.lut_w = c->lut_w; kp.lut_h = c->lut_h;
+    kp.aov_color = (float4*)d_color; kp.aov_albedo = (float4*)d_albedo; kp.aov_normal = (float4*)d_normal;
+    kp.queue_head = (unsigned int*)c->d_work.p;
+    kp.stats = (unsigned long long*)((char*)c->d_work.p + 16);
+    kp.n_lights = c->frame.n_lights;
+    kp.width = p->width; kp.height = p->height; kp.spp = p->spp; kp.frame = p->frame; kp.seed = p->seed; kp.integrator = p->integrator;
+    kp.tiles_x = tiles_x; kp.n_owned_items = (uint32_t)(owned * 64);
+    kp.rank = p->rank; kp.world = world;
+    for (int k = 0; k < 3; k++) {
+        kp.cam_pos[k] = p->camera.pos[k]; kp.cam_dir[k] = p->camera.dir[k];
+        kp.cam_up[k] = p->camera.up[k]; kp.cam_right[k] = p->camera.right[k];
+        kp.sky[k] = p->sky[k] * p->ibl_intensity; // __miss__ms: texel * params.ibl_intensity
+    }
+    kp.cam_f = p->camera.f;
+
+    // persistent grid: blocks_per_cu x #CU workgroups of 4 wavefronts; never more wavefronts than there are pixels to hand out
+    uint64_t want_blocks = (uint64_t)c->n_cus * (uint64_t)c->blocks_per_cu;
+    uint64_t max_useful = (owned * 64 + HJR_BLOCK - 1) / HJR_BLOCK;
+    if (max_useful < 1) max_useful = 1;
+    if (want_blocks > max_useful) want_blocks = max_useful;
+    dim3 grid((unsigned)want_blocks);
+    const bool stats = (p->flags & HJR_FLAG_STATS) != 0;
+
+    HIPCHK(hipEventRecord(c->ev0, st));
+    switch (p->integrator * 2 + (stats ? 1 : 0)) {
+    case 0: launch<HJR_INTEGRATOR_NEE, false>(kp, grid, st); break;
+    case 1: launch<HJR_INTEGRATOR_NEE, true>(kp, grid, st); break;
+    case 2: launch<HJR_INTEGRATOR_PT, false>(kp, grid, st); break;
+    case 3: launch<HJR_INTEGRATOR_PT, true>(kp, grid, st); break;
+    case 4: launch<HJR_INTEGRATOR_MIS, false>(kp, grid, st); break;
+    default: launch<HJR_INTEGRATOR_MIS, true>(kp, grid, st); break;
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(c->ev1, st));
+    c->event_pending = true;
+    return HJR_OK;
+}
+
+static int fetch_stats(hjr_ctx* c, hipStream_t st)
+{
+    unsigned long long h[HJR_NSTAT];
+    HIPCHK(hipMemcpyAsync(h, (char*)c->d_work.p + 16, sizeof(h), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    uint64_t* dst = &c->stats.samples;
+    for (int i = 0; i < HJR_NSTAT; i++) dst[i] = h[i];
+    return HJR_OK;
+}
+
+extern "C" int hjr_render_device(hjr_ctx* c, const hjr_params* p, void* d_color, void* d_albedo, void* d_normal, void* stream)
+{
+    if (!c) { set_error("hjr_render_device: null context"); return HJR_ERR_ARG; }
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    return render_impl(c, p, d_color, d_albedo, d_normal, st);
+}
+
+extern "C" int hjr_synchronize(hjr_ctx* c)
+{
+    if (!c) { set_error("hjr_synchronize: null context"); return HJR_ERR_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipDeviceSynchronize());
+    return HJR_OK;
+}
+
+extern "C" int hjr_get_stats(hjr_ctx* c, hjr_stats* out)
+{
+    if (!c || !out) { set_error("hjr_get_stats: null argument"); return HJR_ERR_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    if (c->event_pending) {
+        HIPCHK(hipEventSynchronize(c->ev1));
+        float ms = 0.0f;
+        HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        c->stats.last_kernel_ms = ms;
+        c->event_pending = false;
+        if (c->d_work.p) { int rc = fetch_stats(c, c->stream); if (rc != HJR_OK) return rc; }
+    }
+    *out = c->stats;
+    return HJR_OK;
+}
+
+extern "C" int hjr_render(hjr_ctx* c, const hjr_params* p, float* color, float* albedo, float* normal)
+{
+    if (!c || !p || !color) { set_error("hjr_render: null argument"); return HJR_ERR_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    const size_t bytes = (size_t)p->width * p->height * 16;
+    if (bytes == 0) { set_error("hjr_render: empty image"); return HJR_ERR_ARG; }
+    DevBuf* bufs[3] = { &c->d_color, &c->d_albedo, &c->d_normal };
+    float* host[3] = { color, albedo, normal };
+    for (int i = 0; i < 3; i++) {
+        if (!host[i]) continue;
+        if (bufs[i]->cap < bytes) {
+            bufs[i]->release();
+            if (hipMalloc(&bufs[i]->p, bytes) != hipSuccess) { set_error("hjr_render: AOV allocation failed"); return HJR_ERR_DEVICE; }
+            bufs[i]->cap = bytes;
+        }
+        HIPCHK(hipMemsetAsync(bufs[i]->p, 0, bytes, c->stream));
+    }
+    int rc = render_impl(c, p, c->d_color.p, albedo ? c->d_albedo.p : nullptr, normal ? c->d_normal.p : nullptr, c->stream);
+    if (rc != HJR_OK) return rc;
+    for (int i = 0; i < 3; i++)
+        if (host[i]) HIPCHK(hipMemcpyAsync(host[i], bufs[i]->p, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream)); // CUDA_SYNC_CHECK (renderer.h:1242)
+    return HJR_OK;
+}

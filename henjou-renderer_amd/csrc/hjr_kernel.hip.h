@@ -1,0 +1,840 @@
+// The Henjou hot path as one persistent-wavefront HIP megakernel for gfx950 (CDNA4):
+//   ray generation -> software BVH2 traversal / triangle test -> BSDF (Disney + thin-film LUT, negative-IOR glass,
+//   multiple-scattering GGX) -> next-event-estimation integrator (also Pathtrace / MIS).
+//
+// Execution model
+//   * one lane owns one pixel and runs its `spp` samples in order, so the per-pixel fp32 sum has a fixed order
+//     (bitwise independent of scheduling, tile sharding and GPU count);
+//   * wavefronts are persistent: a lane whose pixel is finished pulls the next pixel from a global queue with one
+//     wave-aggregated atomic (ballot + mbcnt prefix) — the ray queue never drains until the frame is done;
+//   * paths are regenerated in place: a lane whose path ended (Russian roulette, miss, light hit, depth cap)
+//     starts its next sample in the same loop iteration, so every trace call runs with (nearly) full waves;
+//   * the traversal stack is per lane in LDS ([level][lane] -> conflict-free ds_read/ds_write_b32);
+//   * nodes / triangles / shading records / materials / lights are 16-byte-record arrays fetched as dwordx4.
+//
+// Each device function cites the reference lines it restates (paths relative to the reference's include/).
+#pragma once
+#include "hjr_layout.h"
+#include "hjr_math.hip.h"
+
+struct KParams {
+    const float4* nodes;
+    const float4* tri_geom;
+    const float4* tri_shade;
+    const uint32_t* tri_inst;
+    const float4* materials;
+    const float4* lights;
+    const uchar4* lut;
+    float4* aov_color;
+    float4* aov_albedo;
+    float4* aov_normal;
+    unsigned int* queue_head;
+    unsigned long long* stats;
+    int lut_w, lut_h;
+    uint32_t n_lights;
+    uint32_t width, height, spp, frame, seed, integrator;
+    uint32_t tiles_x, n_owned_items; // items = owned tiles * 64
+    uint32_t rank, world;
+    float cam_pos[3], cam_dir[3], cam_up[3], cam_right[3];
+    float cam_f;
+    float sky[3]; // scene_sky_default * ibl_intensity
+};
+
+// ------------------------------------------------------------------ kernel/cmj.h
+struct CMJState { unsigned long long n_spp; uint32_t scramble, depth, image_idx; }; // cmj.h:53-58
+
+HD uint32_t xxhash32_u4(uint32_t px, uint32_t py, uint32_t pz, uint32_t pw) // cmj.h:38-51
+{
+    const uint32_t P2 = 2246822519U, P3 = 3266489917U, P4 = 668265263U, P5 = 374761393U;
+    uint32_t h = pw + P5 + px * P3;
+    h = P4 * ((h << 17) | (h >> 15));
+    h += py * P3;
+    h = P4 * ((h << 17) | (h >> 15));
+    h += pz * P3;
+    h = P4 * ((h << 17) | (h >> 15));
+    h = P2 * (h ^ (h >> 15));
+    h = P3 * (h ^ (h >> 13));
+    return h ^ (h >> 16);
+}
+HD uint32_t cmj_permute(uint32_t i, uint32_t l, uint32_t p) // cmj.h:60-91
+{
+    uint32_t w = l - 1;
+    w |= w >> 1; w |= w >> 2; w |= w >> 4; w |= w >> 8; w |= w >> 16;
+    do {
+        i ^= p; i *= 0xe170893d;
+        i ^= p >> 16;
+        i ^= (i & w) >> 4;
+        i ^= p >> 8; i *= 0x0929eb3f;
+        i ^= p >> 23;
+        i ^= (i & w) >> 1; i *= 1 | p >> 27;
+        i *= 0x6935fa69;
+        i ^= (i & w) >> 11; i *= 0x74dcb303;
+        i ^= (i & w) >> 2; i *= 0x9e501cc3;
+        i ^= (i & w) >> 2; i *= 0xc860a3df;
+        i &= w;
+        i ^= i >> 5;
+    } while (i >= l);
+    return (i + p) % l;
+}
+HD float cmj_randfloat(uint32_t i, uint32_t p) // cmj.h:93-106
+{
+    i ^= p;
+    i ^= i >> 17; i ^= i >> 10; i *= 0xb36534e5;
+    i ^= i >> 12; i ^= i >> 21; i *= 0x93fc4795;
+    i ^= 0xdf6e307f;
+    i ^= i >> 17; i *= 1 | p >> 18;
+    return i * (1.0f / 4294967808.0f);
+}
+HD f2 cmj(uint32_t index, uint32_t scramble) // cmj.h:108-117
+{
+    index = cmj_permute(index, 16, scramble * 0x51633e2d);
+    uint32_t sx = cmj_permute(index % 4, 4, scramble * 0xa511e9b3);
+    uint32_t sy = cmj_permute(index / 4, 4, scramble * 0x63d83595);
+    float jx = cmj_randfloat(index, scramble * 0xa399d265);
+    float jy = cmj_randfloat(index, scramble * 0x711ad6a5);
+    f2 r;
+    r.x = (index % 4 + (sy + jx) / 4) / 4;
+    r.y = (index / 4 + (sx + jy) / 4) / 4;
+    return r;
+}
+HD f2 cmj_2d(CMJState& st) // cmj.h:119-128
+{
+    const uint32_t index = (uint32_t)(st.n_spp % 16);
+    const uint32_t scramble = xxhash32_u4((uint32_t)(st.n_spp / 16), st.image_idx, st.depth, st.scramble);
+    f2 r = cmj(index, scramble);
+    st.depth++;
+    return r;
+}
+HD float cmj_1d(CMJState& st) { return cmj_2d(st).x; } // cmj.h:130-133
+
+// ------------------------------------------------------------------ kernel/math.h
+HD f3 schlick3(f3 F0, f3 w, f3 n) // math.h:26-29
+{
+    float term1 = 1.0f - dot(w, n);
+    return ssub(1.0f, F0) * p_pow5(term1) + F0;
+}
+HD float schlick_ior(float no, float ni, f3 w, f3 n) // math.h:31-37
+{
+    float F0 = (no - ni) / (no + ni);
+    F0 = F0 * F0;
+    float term1 = 1.0f - dot(w, n);
+    return F0 + (1.0f - F0) * p_pow5(term1);
+}
+HD void orthonormal_basis(f3 n, f3& t, f3& b) // math.h:43-51
+{
+    float sign = copysignf(1.0f, n.z);
+    const float a = -1.0f / (sign + n.z);
+    const float bb = n.x * n.y * a;
+    t = V(1.0f + sign * n.x * n.x * a, sign * bb, -sign * n.x);
+    b = V(bb, sign + n.y * n.y * a, -n.y);
+}
+HD f3 world_to_local(f3 v, f3 t, f3 n, f3 b) { return V(dot(v, t), dot(v, n), dot(v, b)); } // math.h:53-59
+HD f3 local_to_world(f3 v, f3 t, f3 n, f3 b) // math.h:61-71
+{
+    return V(v.x * t.x + v.y * n.x + v.z * b.x, v.x * t.y + v.y * n.y + v.z * b.y, v.x * t.z + v.y * n.z + v.z * b.z);
+}
+HD float norm2(f3 v) { return v.x * v.x + v.y * v.y + v.z * v.z; } // math.h:88-90
+HD bool refract3(f3 v, f3 n, float ior1, float ior2, f3& r) // math.h:92-103
+{
+    const f3 t_h = (v - n * dot(v, n)) * (-ior1 / ior2);
+    if (norm2(t_h) > 1.0f) return false;
+    const f3 t_p = n * (-sqrtf(fmaxf(1.0f - norm2(t_h), 0.0f)));
+    r = t_h + t_p;
+    return true;
+}
+
+// ------------------------------------------------------------------ surface record: the fields of Payload the BSDFs read
+struct Surface { // kernel/Payload.h:12-42
+    f3 basecolor;
+    float metallic, roughness, sheen, clearcoat, ior;
+    bool is_specular, is_thinfilm;
+};
+
+// ------------------------------------------------------------------ thin-film LUT: tex2D<float4>(params.lut_texture, u, v), disneyBRDF.h:11-14
+// Sampler state from renderer.h:854-898 (uchar4 -> normalised float, linear, wrap, normalised coords); filtering per the
+// CUDA programming guide: texel-centre offset, 1.8 fixed-point weights.
+HD f3 lut_fetch(const KParams& P, float u, float v)
+{
+    if (!P.lut || P.lut_w <= 0 || P.lut_h <= 0) return V1(0.0f);
+    int w = P.lut_w, h = P.lut_h;
+    float x = u * (float)w - 0.5f, y = v * (float)h - 0.5f;
+    float fx = floorf(x), fy = floorf(y);
+    float ax = floorf((x - fx) * 256.0f + 0.5f) * (1.0f / 256.0f);
+    float ay = floorf((y - fy) * 256.0f + 0.5f) * (1.0f / 256.0f);
+    int i0 = (int)fx % w; if (i0 < 0) i0 += w;
+    int j0 = (int)fy % h; if (j0 < 0) j0 += h;
+    int i1 = (i0 + 1) % w, j1 = (j0 + 1) % h;
+    uchar4 c00 = P.lut[j0 * w + i0], c10 = P.lut[j0 * w + i1], c01 = P.lut[j1 * w + i0], c11 = P.lut[j1 * w + i1];
+    float w00 = (1.0f - ax) * (1.0f - ay), w10 = ax * (1.0f - ay), w01 = (1.0f - ax) * ay, w11 = ax * ay;
+    const float k = 1.0f / 255.0f;
+    f3 r;
+    r.x = w00 * ((float)c00.x * k) + w10 * ((float)c10.x * k) + w01 * ((float)c01.x * k) + w11 * ((float)c11.x * k);
+    r.y = w00 * ((float)c00.y * k) + w10 * ((float)c10.y * k) + w01 * ((float)c01.y * k) + w11 * ((float)c11.y * k);
+    r.z = w00 * ((float)c00.z * k) + w10 * ((float)c10.z * k) + w01 * ((float)c01.z * k) + w11 * ((float)c11.z * k);
+    return r;
+}
+
+// ------------------------------------------------------------------ DisneyBRDF (kernel/disneyBRDF.h:16-327)
+#define HJ_LOG_CLEARCOAT_ALPHA2 (-13.8155105579642741f) /* logf(0.001f*0.001f): the only argument clearcoat_D ever sees */
+#define HJ_CLEARCOAT_ALPHA 0.001f                          /* lerp(0.1f, 0.001f, 1.0f) with math.h:109-111 */
+
+struct Disney {
+    f3 basecolor;
+    float alpha, metallic, sheen, clearcoat;
+    bool is_thinfilm;
+};
+HD Disney disney_init(const Surface& s) // :165-177
+{
+    Disney d;
+    d.basecolor = s.basecolor;
+    d.alpha = clampf(s.roughness * s.roughness, 0.01f, 1.0f);
+    d.metallic = s.metallic;
+    d.sheen = s.sheen;
+    d.clearcoat = s.clearcoat;
+    d.is_thinfilm = s.is_thinfilm;
+    return d;
+}
+HD float ggx_D(float a, f3 wm) // :44-48 (same body in BSDFs.h:507-511)
+{
+    float term1 = wm.x * wm.x / (a * a) + wm.z * wm.z / (a * a) + wm.y * wm.y;
+    float term2 = HJ_PI * a * a * term1 * term1;
+    return 1.0f / term2;
+}
+HD float d_Lambda(float a, f3 w) // :58-61
+{
+    float delta = 1.0f + (a * a * w.x * w.x + a * a * w.z * w.z) / (w.y * w.y);
+    return (-1.0f + sqrtf(delta)) * 0.5f;
+}
+HD float d_G1(float a, f3 w) { return 1.0f / (1.0f + d_Lambda(a, w)); }                             // :50-52
+HD float d_G2(float a, f3 wi, f3 wo) { return 1.0f / (1.0f + d_Lambda(a, wi) + d_Lambda(a, wo)); }   // :54-56
+HD float d_getPDFDiffuse(f3 wi) { return fabsf(wi.y) * HJ_INV_PI; }                                  // :40-42
+HD f3 d_sampleDiffuse(f2 uv, float& pdf) // :30-38
+{
+    float theta = 0.5f * p_acos(1.0f - 2.0f * uv.x);
+    float phi = 2.0f * HJ_PI * uv.y;
+    float sinTheta, cosTheta, sp, cp;
+    p_sincos(theta, sinTheta, cosTheta);
+    p_sincos(phi, sp, cp);
+    f3 wi = V(cp * sinTheta, cosTheta, sp * sinTheta);
+    pdf = d_getPDFDiffuse(wi);
+    return wi;
+}
+// spherical-cap VNDF sampling (arXiv 2306.05044): disneyBRDF.h:64-80 == BSDFs.h:616-632
+HD f3 sample_visible_normal(float alpha, f2 uv, f3 wo)
+{
+    f3 strech_wo = normalize(V(wo.x * alpha, wo.y, wo.z * alpha));
+    float phi = 2.0f * HJ_PI * uv.x;
+    float z = fmaf((1.0f - uv.y), (1.0f + strech_wo.y), -strech_wo.y);
+    float sinTheta = sqrtf(clampf(1.0f - z * z, 0.0f, 1.0f));
+    float sp, cp;
+    p_sincos(phi, sp, cp);
+    float x = cp * sinTheta;
+    float y = sp * sinTheta;
+    f3 c = V(x, z, y);
+    f3 h = c + strech_wo;
+    return normalize(V(h.x * alpha, h.y, h.z * alpha));
+}
+HD float d_getPDFSpecular(float a, f3 wm, f3 wo) // :88-90
+{
+    return 0.25f * ggx_D(a, wm) * d_G1(a, wo) * absdot(wo, wm) / (absdot(wm, wo) * fabsf(wo.y));
+}
+HD float clearcoat_D(f3 wm, float alpha) // :131-139
+{
+    float alpha2 = alpha * alpha;
+    float t = 1.0f + (alpha2 - 1.0f) * wm.y * wm.y;
+    return (alpha2 - 1.0f) / (HJ_PI * HJ_LOG_CLEARCOAT_ALPHA2 * t);
+}
+HD float d_getPDFClearcoat(f3 wm, f3 wo) // :102-104
+{
+    return clearcoat_D(wm, HJ_CLEARCOAT_ALPHA) * fabsf(wm.y) / (4.0f * fabsf(dot(wm, wo)));
+}
+HD f3 d_sampleClearcoat(f2 uv, f3 wo, float& pdf) // :93-100
+{
+    const float ca = HJ_CLEARCOAT_ALPHA;
+    float cosineTheta = sqrtf(fmaxf((1.0f - p_pow(ca * ca, 1.0f - uv.x)) / (1.0f - ca * ca), 0.0f));
+    float sinTheta = sqrtf(fmaxf(1.0f - cosineTheta * cosineTheta, 0.0f));
+    float phi = HJ_PI2 * uv.y;
+    float sp, cp;
+    p_sincos(phi, sp, cp);
+    f3 wm = V(cp * sinTheta, cosineTheta, sp * sinTheta);
+    pdf = d_getPDFClearcoat(wm, wo);
+    return wm;
+}
+HD float f_tSchlick(float wn, float F90) // :106-109
+{
+    float delta = fmaxf(1.0f - wn, 0.0f);
+    return 1.0f + (F90 - 1.0f) * delta * delta * delta * delta * delta;
+}
+HD float clearcoat_Lambda(f3 w, float alpha) // :126-129
+{
+    float term1 = 1.0f + (alpha * alpha * w.x * w.x + alpha * alpha * w.z * w.z) / (w.y * w.y);
+    return 0.5f * (-1.0f + sqrtf(term1));
+}
+HD f3 disney_eval(const KParams& P, const Disney& d, f3 wo, f3 wi) // :179-235
+{
+    f3 wm = normalize(wo + wi);
+    float dot_wi_n = fabsf(wi.y);
+    float dot_wo_n = fabsf(wi.y); // sic (:189)
+    float cosine_d = absdot(wi, wm);
+    float F_D90 = 0.5f + 2.0f * d.alpha * cosine_d * cosine_d;
+    float f_tsi = f_tSchlick(dot_wi_n, F_D90);
+    float f_tso = f_tSchlick(dot_wo_n, F_D90);
+    f3 f_diffuse = d.basecolor * f_tsi * f_tso * HJ_INV_PI;
+    float deltacos = 1.0f / (dot_wi_n + dot_wo_n) - 0.5f;
+    f3 f_subsurface = d.basecolor * HJ_INV_PI * 1.25f * (f_tsi * f_tso * deltacos + 0.5f);
+    f3 F0 = lerp3(V1(0.08f), d.basecolor, d.metallic);
+    if (d.is_thinfilm) { // :213-217
+        float thickness = d.basecolor.x;
+        float cosine = absdot(wi, wm);
+        F0 = lut_fetch(P, thickness, cosine);
+    }
+    // specular(), :112-120
+    f3 f_specular;
+    {
+        float ggxD = ggx_D(d.alpha, wm);
+        float ggxG = d_G2(d.alpha, wi, wo);
+        f3 ggxF = schlick3(F0, wo, wm);
+        f_specular = (ggxF * 0.25f * ggxD * ggxG) / (fabsf(wo.y) * fabsf(wi.y));
+    }
+    float delta = fmaxf(1.0f - absdot(wi, wm), 0.0f);
+    f3 f_sheen = V1(1.0f) * d.sheen * delta * delta * delta * delta * delta;
+    // clearcoat(), :142-150
+    f3 f_clearcoat;
+    {
+        float cD = clearcoat_D(wm, HJ_CLEARCOAT_ALPHA);
+        float cG = 1.0f / (1.0f + clearcoat_Lambda(wi, 0.25f) + clearcoat_Lambda(wo, 0.25f));
+        f3 cF = schlick3(V1(0.04f), wo, wm);
+        f_clearcoat = ((cF * (0.25f * cD * cG)) / (fabsf(wo.y) * fabsf(wi.y))) * 0.25f;
+    }
+    // m_subsurface is forced to 0 (:170): lerp(f_diffuse, f_subsurface, 0) = f_diffuse + (f_subsurface - f_diffuse) * 0
+    return (lerp3(f_diffuse, f_subsurface, 0.0f) + f_sheen) * (1.0f - d.metallic) + f_specular + f_clearcoat * d.clearcoat;
+}
+HD f3 disney_sample(const KParams& P, const Disney& d, f3 wo, f3& wi, float& pdf, CMJState& st) // :237-307
+{
+    float diffuseWeight = 1.0f * (1.0f - d.metallic);
+    float specularWeight = 0.5f;
+    float clearcoatWeight = 0.0f;
+    float sumWeight = diffuseWeight + specularWeight + clearcoatWeight;
+    float dw = diffuseWeight / sumWeight;
+    float sw = specularWeight / sumWeight;
+    float cw = clearcoatWeight / sumWeight;
+    float select_p = cmj_1d(st);
+    float pdf_diffuse = 1.0f, pdf_specular = 1.0f, pdf_clearcoat = 1.0f;
+    f2 xi = cmj_2d(st);
+    if (select_p < dw) {
+        wi = d_sampleDiffuse(xi, pdf_diffuse);
+        f3 wm = normalize(wi + wo);
+        pdf_specular = d_getPDFSpecular(d.alpha, wm, wo);
+        pdf_clearcoat = d_getPDFClearcoat(wm, wo);
+    } else if (select_p < dw + sw) {
+        f3 wm = sample_visible_normal(d.alpha, xi, wo);
+        pdf_specular = d_getPDFSpecular(d.alpha, wm, wo);
+        wi = reflect3(-wo, wm);
+        pdf_diffuse = d_getPDFDiffuse(wi);
+        pdf_clearcoat = d_getPDFClearcoat(wm, wo);
+    } else {
+        f3 wm = d_sampleClearcoat(xi, wo, pdf_clearcoat);
+        wi = reflect3(-wo, wm);
+        pdf_diffuse = d_getPDFDiffuse(wi);
+        pdf_specular = d_getPDFSpecular(d.alpha, wm, wo);
+    }
+    pdf = dw * pdf_diffuse + sw * pdf_specular + cw * pdf_clearcoat;
+    if (wi.y < 0.0f) { pdf = 1.0f; return V1(0.0f); }
+    return disney_eval(P, d, wo, wi);
+}
+HD float disney_pdf(const Disney& d, f3 wo, f3 wi) // :309-326
+{
+    float diffuseWeight = 1.0f * (1.0f - d.metallic);
+    float specularWeight = 0.5f, clearcoatWeight = 0.0f;
+    float sumWeight = diffuseWeight + specularWeight + clearcoatWeight;
+    float dw = diffuseWeight / sumWeight, sw = specularWeight / sumWeight;
+    f3 wm = normalize(wo + wi);
+    return dw * d_getPDFDiffuse(wi) + sw * d_getPDFSpecular(d.alpha, wm, wo);
+}
+
+// ------------------------------------------------------------------ MetaMaterialGlass (kernel/BSDFs.h:404-479): negative refractive index
+HD f3 metaglass_sample(float ior, f3 wo, f3& wi, float& pdf, CMJState& st)
+{
+    const f3 rho = V1(1.0f); // BSDFs.h:998
+    float ior_o = 1.0f, ior_i = ior, sign = 1.0f;
+    f3 lwo = wo, lwi;
+    f3 n = V(0, 1, 0);
+    if (wo.y < 0.0f) { ior_o = ior; ior_i = 1.0f; lwo.y = -lwo.y; sign = -1.0f; }
+    const float fr = schlick_ior(ior_o, ior_i, lwo, n);
+    float p = cmj_1d(st);
+    f3 t;
+    if (p < fr) lwi = reflect3(-lwo, n);
+    else if (refract3(lwo, n, ior_o, ior_i, t)) lwi = reflect3(-t, V(0, -1, 0)); // tangential flip (:454)
+    else lwi = reflect3(-lwo, n);
+    pdf = 1;
+    f3 evalbsdf = rho / fabsf(lwi.y);
+    wi = lwi;
+    wi.y = sign * wi.y;
+    return evalbsdf;
+}
+
+// ------------------------------------------------------------------ EnagyConservationGGX (kernel/BSDFs.h:483-852): Heitz multiple-scattering walk
+HD float ms_C1(float h) { return fminf(1.0f, fmaxf(0.0f, 0.5f * (h + 1.0f))); }        // :494-500
+HD float ms_invC1(float U) { return fmaxf(-1.0f, fminf(1.0f, 2.0f * U - 1.0f)); }      // :502-505
+HD float ms_Lambda(float a, f3 v) // :525-532 (the -1.0 / 2.0f literals make this a double expression)
+{
+    if (v.y > 0.9999f) return 0.0f;
+    if (v.y < -0.9999f) return -1.0f;
+    float delta = 1.0f + (a * a * v.x * v.x + a * a * v.z * v.z) / (v.y * v.y);
+    float sg = (v.y > 0.0f) ? 1.0f : -1.0f;
+    return (float)((-1.0 + (double)(sg * sqrtf(delta))) / (double)2.0f);
+}
+HD float ms_G1_Height(float a, f3 wi, float h0) // :551-563
+{
+    if (wi.y > 0.9999f) return 1.0f;
+    if (wi.y <= 0.0f) return 0.0f;
+    const float C1_h0 = ms_C1(h0);
+    const float Lambda = ms_Lambda(a, wi);
+    return p_pow(C1_h0, Lambda);
+}
+HD float ms_sampleHeight(float a, f3 wr, float hr, float U) // :566-586
+{
+    if (wr.y > 0.9999f) return HJ_FLT_MAX;
+    if (wr.y < -0.9999f) return ms_invC1(U * ms_C1(hr));
+    if (fabsf(wr.y) < 0.0001f) return hr;
+    const float G_1_ = ms_G1_Height(a, wr, hr);
+    if (U > 1.0f - G_1_) return HJ_FLT_MAX;
+    return ms_invC1(ms_C1(hr) / p_pow((1.0f - U), 1.0f / ms_Lambda(a, wr)));
+}
+HD f3 msggx_sampleBSDF(f3 F0, float alpha, f3 wo_in, f3& wi_out, CMJState& st, float& pdf) // :784-819 + :843-851
+{
+    f3 wr = -wo_in;
+    float hr = 1.0f + ms_invC1(0.999f);
+    int order = 0;
+    f3 weight = V1(1.0f);
+    bool early = false;
+    f3 early_ret = V1(0.0f);
+    for (;;) {
+        float U = cmj_1d(st);
+        hr = ms_sampleHeight(alpha, wr, hr, U);
+        if (hr == HJ_FLT_MAX) break;
+        else order++;
+        if (order > 5) { wi_out = V(0, 0, 1); early = true; early_ret = V(0, 0, 0); break; }
+        // samplePhaseFunction(-wr, state, weight_1), :737-746
+        f3 wi = -wr;
+        const f2 uv = cmj_2d(st);
+        f3 wm = sample_visible_normal(alpha, uv, wi);
+        wr = (-wi) + (wm * 2.0f) * dot(wi, wm);
+        f3 weight_1 = schlick3(F0, wi, wm);
+        weight = weight * weight_1;
+        if ((hr != hr) || (wr.z != wr.z)) { early = true; early_ret = V(0, 0, 1); break; } // wi_out untouched (:813-814)
+    }
+    f3 bsdf;
+    if (early) bsdf = early_ret;
+    else { wi_out = wr; bsdf = weight; }
+    if (wi_out.y < 0.0f || order > 5) return V1(0.0f); // pdf stays as the caller initialised it (:846-848)
+    pdf = fabsf(wi_out.y);
+    return bsdf;
+}
+
+// ------------------------------------------------------------------ BSDF dispatch (kernel/BSDFs.h:979-1038)
+HD f3 bsdf_eval(const KParams& P, const Surface& s, f3 wo, f3 wi)
+{
+    if (s.is_specular) return V1(0.0f);
+    Disney d = disney_init(s);
+    return disney_eval(P, d, wo, wi);
+}
+HD f3 bsdf_sample(const KParams& P, const Surface& s, f3 wo, f3& wi, float& pdf, CMJState& st)
+{
+    if (s.is_specular) return metaglass_sample(s.ior, wo, wi, pdf, st);
+    if (!(s.metallic > 0.5f)) {
+        Disney d = disney_init(s);
+        return disney_sample(P, d, wo, wi, pdf, st);
+    }
+    return msggx_sampleBSDF(s.basecolor, clampf(s.roughness * s.roughness, 0.0001f, 1.0f), wo, wi, st, pdf);
+}
+HD float bsdf_pdf(const Surface& s, f3 wo, f3 wi)
+{
+    if (s.is_specular) return 0.0f;
+    Disney d = disney_init(s);
+    return disney_pdf(d, wo, wi);
+}
+
+// ------------------------------------------------------------------ traversal: replaces optixTrace (kernel/rt.h:15-69) + RT cores
+struct Counters { uint32_t box, tri; };
+
+HD float dotf(f3 a, f3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+HD f3 crossf(f3 a, f3 b)
+{
+    return V(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
+}
+// canonical ray/triangle test — the same operation sequence as the oracle's ray_tri()
+HD bool ray_tri(f3 v0, f3 v1, f3 v2, f3 o, f3 d, float tmin, float tmax, float& t, float& b1, float& b2)
+{
+    f3 e1 = v1 - v0, e2 = v2 - v0;
+    f3 p = crossf(d, e2);
+    float det = dotf(e1, p);
+    if (det == 0.0f) return false;
+    float inv = 1.0f / det;
+    f3 tv = o - v0;
+    float u = dotf(tv, p) * inv;
+    if (!(u >= 0.0f && u <= 1.0f)) return false;
+    f3 q = crossf(tv, e1);
+    float v = dotf(d, q) * inv;
+    if (!(v >= 0.0f && u + v <= 1.0f)) return false;
+    float tt = dotf(e2, q) * inv;
+    if (!(tt > tmin && tt < tmax)) return false;
+    t = tt; b1 = u; b2 = v;
+    return true;
+}
+
+struct Hit { float t, b1, b2; uint32_t k, prim; };
+
+// stack: this lane's column of the LDS stack, element i at stack[i * BLOCK]
+template <bool ANY, bool STATS, int BLOCK>
+HD bool traverse(const KParams& P, f3 o, f3 d, float tmin, float tmax, Hit& hit, uint32_t* stack, Counters& cnt)
+{
+    const f3 inv = V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    int sp = 0;
+    uint32_t cur = 0;
+    hit.prim = 0xffffffffu;
+    hit.t = tmax;
+    for (;;) {
+        if (!(cur & HJR_LEAF_FLAG)) {
+            const float4* nd = P.nodes + (size_t)cur * HJR_NODE_F4;
+            const float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
+            const float tfar = hit.t;
+            // child 0: lo (q0.x q0.y q0.z) hi (q0.w q1.x q1.y)
+            float t0 = (q0.x - o.x) * inv.x, t1 = (q0.w - o.x) * inv.x;
+            float lo0 = fminf(t0, t1), hi0 = fmaxf(t0, t1);
+            t0 = (q0.y - o.y) * inv.y; t1 = (q1.x - o.y) * inv.y;
+            lo0 = fmaxf(lo0, fminf(t0, t1)); hi0 = fminf(hi0, fmaxf(t0, t1));
+            t0 = (q0.z - o.z) * inv.z; t1 = (q1.y - o.z) * inv.z;
+            lo0 = fmaxf(lo0, fminf(t0, t1)); hi0 = fminf(hi0, fmaxf(t0, t1));
+            lo0 = fmaxf(lo0, tmin); hi0 = fminf(hi0, tfar);
+            // child 1: lo (q1.z q1.w q2.x) hi (q2.y q2.z q2.w)
+            t0 = (q1.z - o.x) * inv.x; t1 = (q2.y - o.x) * inv.x;
+            float lo1 = fminf(t0, t1), hi1 = fmaxf(t0, t1);
+            t0 = (q1.w - o.y) * inv.y; t1 = (q2.z - o.y) * inv.y;
+            lo1 = fmaxf(lo1, fminf(t0, t1)); hi1 = fminf(hi1, fmaxf(t0, t1));
+            t0 = (q2.x - o.z) * inv.z; t1 = (q2.w - o.z) * inv.z;
+            lo1 = fmaxf(lo1, fminf(t0, t1)); hi1 = fminf(hi1, fmaxf(t0, t1));
+            lo1 = fmaxf(lo1, tmin); hi1 = fminf(hi1, tfar);
+            const bool h0 = lo0 <= hi0 * 1.0000004f, h1 = lo1 <= hi1 * 1.0000004f;
+            const uint32_t c0 = f2bits(q3.x), c1 = f2bits(q3.y);
+            if (STATS) cnt.box += 2;
+            if (h0 && h1) {
+                const bool swap = lo1 < lo0;
+                stack[sp * BLOCK] = swap ? c0 : c1;
+                sp++;
+                cur = swap ? c1 : c0;
+                continue;
+            }
+            if (h0) { cur = c0; continue; }
+            if (h1) { cur = c1; continue; }
+        } else {
+            const uint32_t first = cur & 0x07ffffffu, count = (cur >> 27) & 15u;
+            for (uint32_t i = 0; i < count; i++) {
+                const float4* g = P.tri_geom + (size_t)(first + i) * HJR_TRI_F4;
+                const float4 g0 = g[0], g1 = g[1], g2 = g[2];
+                float t, b1, b2;
+                if (STATS) cnt.tri++;
+                if (ray_tri(V(g0.x, g0.y, g0.z), V(g0.w, g1.x, g1.y), V(g1.z, g1.w, g2.x), o, d, tmin, tmax, t, b1, b2)) {
+                    if (ANY) return true;
+                    const uint32_t prim = f2bits(g2.y);
+                    // order-independent closest-hit rule: smaller t wins; equal t -> smaller global prim id
+                    if (hit.prim == 0xffffffffu || t < hit.t || (t == hit.t && prim < hit.prim)) {
+                        hit.t = t; hit.b1 = b1; hit.b2 = b2; hit.k = first + i; hit.prim = prim;
+                    }
+                }
+            }
+        }
+        if (sp == 0) break;
+        sp--;
+        cur = stack[sp * BLOCK];
+    }
+    return hit.prim != 0xffffffffu;
+}
+
+// ------------------------------------------------------------------ closest-hit / miss programs (build-defined)
+struct HitInfo { // the Payload fields the integrators read (kernel/Payload.h:12-42)
+    bool is_hit, is_light;
+    f3 position, normal, emission;
+    Surface surf;
+    uint32_t prim;
+};
+
+template <bool STATS, int BLOCK>
+HD void ray_trace(const KParams& P, f3 o, f3 d, HitInfo& prd, uint32_t* stack, unsigned long long* lc)
+{
+    Hit h;
+    Counters c; c.box = 0; c.tri = 0;
+    const bool got = traverse<false, STATS, BLOCK>(P, o, d, 0.001f, 1e16f, h, stack, c);
+    if (STATS) { lc[1] += 1; lc[3] += c.box; lc[4] += c.tri; }
+    if (!got) { // __miss__ms: constant sky (use_IBL = false: 1x1 texel scene_sky_default, renderer.h:802-851) * ibl_intensity
+        prd.is_hit = false; prd.is_light = false;
+        prd.emission = V(P.sky[0], P.sky[1], P.sky[2]);
+        prd.position = V1(0.0f); prd.normal = V1(0.0f);
+        prd.surf.basecolor = V1(0.0f); // Payload default (Payload.h:25)
+        prd.prim = 0xffffffffu;
+        return;
+    }
+    // __closesthit__ch: barycentric interpolation of the pre-transformed vertices / normals with (1-b1-b2, b1, b2);
+    // the interpolated normal is neither re-normalised nor flipped (stale ptx:1244-1283)
+    const float4* g = P.tri_geom + (size_t)h.k * HJR_TRI_F4;
+    const float4 g0 = g[0], g1 = g[1], g2 = g[2];
+    const float4* s = P.tri_shade + (size_t)h.prim * HJR_SHADE_F4;
+    const float4 s0 = s[0], s1 = s[1], s2 = s[2], s3 = s[3];
+    const float w0 = 1.0f - h.b1 - h.b2;
+    prd.is_hit = true;
+    prd.position = V(g0.x, g0.y, g0.z) * w0 + V(g0.w, g1.x, g1.y) * h.b1 + V(g1.z, g1.w, g2.x) * h.b2;
+    prd.normal = V(s0.x, s0.y, s0.z) * w0 + V(s1.x, s1.y, s1.z) * h.b1 + V(s2.x, s2.y, s2.z) * h.b2;
+    const float4* m = P.materials + (size_t)f2bits(s3.w) * HJR_MAT_F4;
+    const float4 m0 = m[0], m1 = m[1], m2 = m[2], m3 = m[3];
+    prd.surf.basecolor = V(m0.x, m0.y, m0.z);
+    prd.surf.metallic = m0.w;
+    prd.surf.roughness = m1.x; prd.surf.sheen = m1.y; prd.surf.clearcoat = m1.z; prd.surf.ior = m1.w;
+    prd.emission = V(m2.y, m2.z, m2.w);
+    prd.is_light = f2bits(m3.x) != 0;
+    prd.surf.is_specular = f2bits(m3.y) != 0;
+    prd.surf.is_thinfilm = f2bits(m3.z) != 0;
+    prd.prim = h.prim;
+    if (STATS) lc[7] += 1;
+}
+
+// light_sample (kernel/light_sample.h:9-75) on the per-frame light table
+HD f3 light_sample(const KParams& P, CMJState& st, float& pdf, f3& normal, f3& emission)
+{
+    float p = cmj_1d(st);
+    int index = (int)(p * P.n_lights);
+    if (index == (int)P.n_lights) index--;
+    const float4* L = P.lights + (size_t)index * HJR_LIGHT_F4;
+    const float4 l0 = L[0], l1 = L[1], l2 = L[2], l3 = L[3], l4 = L[4], l5 = L[5];
+    f2 xi = cmj_2d(st);
+    float f1 = 1.0f - sqrtf(xi.x);
+    float f2_ = sqrtf(xi.x) * (1.0f - xi.y);
+    float f3_ = sqrtf(xi.x) * xi.y;
+    const f3 light_position = V(l0.x, l0.y, l0.z) * f1 + V(l1.x, l1.y, l1.z) * f2_ + V(l2.x, l2.y, l2.z) * f3_;
+    normal = normalize(V(l3.x, l3.y, l3.z) * f1 + V(l4.x, l4.y, l4.z) * f2_ + V(l5.x, l5.y, l5.z) * f3_);
+    pdf = l0.w;
+    emission = V(l1.w, l2.w, l3.w);
+    return light_position;
+}
+
+// ------------------------------------------------------------------ the megakernel
+#define HJR_BLOCK 256
+#define HJR_INTEGRATOR_NEE_ 0
+#define HJR_INTEGRATOR_PT_ 1
+#define HJR_INTEGRATOR_MIS_ 2
+
+struct PathState {
+    f3 ro, rd, thr, L;
+    CMJState st;
+    int depth;
+};
+
+// __raygen__rg for one sample (build-defined; SURVEY §8a a1/a2, stale ptx:33-106): CMJ stream keyed by
+// (frame * spp + s, seed, pixel), first 2-D draw = sub-pixel jitter, u = (2(x+jx) - W) / H, v = (2(y+jy) - H) / H
+HD void start_path(const KParams& P, PathState& ps, uint32_t px, uint32_t py, uint32_t s)
+{
+    ps.st.n_spp = (unsigned long long)P.frame * (unsigned long long)P.spp + (unsigned long long)s;
+    ps.st.scramble = P.seed;
+    ps.st.depth = 0;
+    ps.st.image_idx = px + py * P.width;
+    f2 j = cmj_2d(ps.st);
+    float W = (float)P.width, H = (float)P.height;
+    float u = (2.0f * ((float)px + j.x) - W) / H;
+    float v = (2.0f * ((float)py + j.y) - H) / H;
+    f3 cd = V(P.cam_dir[0], P.cam_dir[1], P.cam_dir[2]);
+    f3 cu = V(P.cam_up[0], P.cam_up[1], P.cam_up[2]);
+    f3 cr = V(P.cam_right[0], P.cam_right[1], P.cam_right[2]);
+    ps.ro = V(P.cam_pos[0], P.cam_pos[1], P.cam_pos[2]);
+    ps.rd = normalize(cd * P.cam_f + cr * u + cu * v);
+    ps.thr = V1(1.0f);
+    ps.L = V1(0.0f);
+    ps.depth = 0;
+}
+
+template <int INTEGRATOR, bool STATS>
+__global__ void __launch_bounds__(HJR_BLOCK) hjr_render_kernel(const KParams P)
+{
+    __shared__ uint32_t s_stack[HJR_STACK_DEPTH * HJR_BLOCK];
+    uint32_t* stack = s_stack + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+
+    unsigned long long lc[HJR_NSTAT];
+    if (STATS) for (int i = 0; i < HJR_NSTAT; i++) lc[i] = 0;
+
+    bool has_pixel = false, dead = false, path_live = false;
+    uint32_t px = 0, py = 0, s = 0;
+    f3 sumL = V1(0.0f), sumA = V1(0.0f), sumN = V1(0.0f);
+    PathState ps;
+    ps.ro = ps.rd = ps.thr = ps.L = V1(0.0f);
+    ps.depth = 0;
+    ps.st.n_spp = 0; ps.st.scramble = 0; ps.st.depth = 0; ps.st.image_idx = 0;
+    const float inv_spp = 1.0f / (float)P.spp;
+
+    for (;;) {
+        // ---- ray-queue refill: one wave-aggregated atomic hands out pixels to every idle lane (ballot + mbcnt prefix)
+        {
+            const bool need = !has_pixel && !dead;
+            const unsigned long long m = __ballot(need);
+            if (m) {
+                const uint32_t n = (uint32_t)__popcll(m);
+                const uint32_t leader = (uint32_t)(__ffsll((long long)m) - 1);
+                uint32_t base = 0;
+                if (lane == leader) base = atomicAdd(P.queue_head, n);
+                base = (uint32_t)__shfl((int)base, (int)leader);
+                const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                if (need) {
+                    const uint32_t q = base + prefix;
+                    if (q < P.n_owned_items) {
+                        const uint32_t tile = (q >> 6) * P.world + P.rank;
+                        const uint32_t tx = tile % P.tiles_x, ty = tile / P.tiles_x;
+                        px = tx * HJR_TILE + (q & 7u);
+                        py = ty * HJR_TILE + ((q >> 3) & 7u);
+                        if (px < P.width && py < P.height) {
+                            has_pixel = true; path_live = false; s = 0;
+                            sumL = V1(0.0f); sumA = V1(0.0f); sumN = V1(0.0f);
+                        }
+                    } else dead = true;
+                }
+            }
+            if (__ballot(!dead) == 0ull) break;
+        }
+
+        // end of a path: NaN/Inf guard, ordered accumulation, next sample or pixel write-out
+        auto end_path = [&]() {
+            float sum = ps.L.x + ps.L.y + ps.L.z;
+            if (!(sum - sum == 0.0f)) { ps.L = V1(0.0f); if (STATS) lc[9] += 1; }
+            sumL = sumL + ps.L;
+            if (STATS) lc[0] += 1;
+            s++;
+            path_live = false;
+            if (s == P.spp) {
+                const size_t pix = (size_t)px + (size_t)py * P.width;
+                P.aov_color[pix] = make_float4(sumL.x * inv_spp, sumL.y * inv_spp, sumL.z * inv_spp, 1.0f);
+                if (P.aov_albedo) P.aov_albedo[pix] = make_float4(sumA.x * inv_spp, sumA.y * inv_spp, sumA.z * inv_spp, 1.0f);
+                if (P.aov_normal) P.aov_normal[pix] = make_float4(sumN.x * inv_spp, sumN.y * inv_spp, sumN.z * inv_spp, 1.0f);
+                has_pixel = false;
+            }
+        };
+
+        // ---- Russian roulette (rt.h:173-179) with in-place path regeneration: a lane whose path dies here starts its
+        //      next sample immediately, so it still has a ray for this iteration's trace
+        bool tracing = false;
+        while (has_pixel) {
+            if (!path_live) { start_path(P, ps, px, py, s); path_live = true; }
+            const float russian_p = fmaxf(ps.thr.x, fmaxf(ps.thr.y, ps.thr.z));
+            if (russian_p < cmj_1d(ps.st)) { end_path(); continue; }
+            ps.thr = ps.thr / russian_p;
+            tracing = true;
+            break;
+        }
+
+        if (tracing) {
+            HitInfo prd;
+            ray_trace<STATS, HJR_BLOCK>(P, ps.ro, ps.rd, prd, stack, lc);
+            if (ps.depth == 0) { sumA = sumA + prd.surf.basecolor; sumN = sumN + prd.normal; } // rt.h:191-194
+            if (!prd.is_hit || prd.is_light) {
+                // NEE / MIS count emission only at depth 0 (rt.h:196-208, 318-330); Pathtrace always (rt.h:118-126)
+                if (INTEGRATOR == HJR_INTEGRATOR_PT_ || ps.depth == 0) ps.L = ps.L + ps.thr * prd.emission;
+                end_path();
+            } else {
+                const Surface& sf = prd.surf;
+                f3 t, b;
+                const f3 n = prd.normal;
+                orthonormal_basis(n, t, b);
+                const f3 local_wo = world_to_local(-ps.rd, t, n, b);
+
+                if (INTEGRATOR != HJR_INTEGRATOR_PT_ && P.n_lights >= 1u) { // light_prim_count < 1: no contribution (UB in the reference)
+                    float light_pdf;
+                    f3 light_color, light_normal;
+                    const f3 light_position = light_sample(P, ps.st, light_pdf, light_normal, light_color);
+                    if (STATS) lc[8] += 1;
+                    const f3 so = prd.position;
+                    f3 sd;
+                    float light_distance;
+                    if (INTEGRATOR == HJR_INTEGRATOR_NEE_) { // rt.h:230-233
+                        sd = normalize(light_position - so);
+                        light_distance = length3(light_position - so);
+                    } else { // rt.h:352-354
+                        sd = light_position - so;
+                        light_distance = length3(sd);
+                        sd = normalize(sd);
+                    }
+                    Hit sh;
+                    Counters c; c.box = 0; c.tri = 0;
+                    const bool occluded = traverse<true, STATS, HJR_BLOCK>(P, so, sd, 0.001f, light_distance - 0.001f, sh, stack, c);
+                    if (STATS) { lc[2] += 1; lc[5] += c.box; lc[6] += c.tri; }
+                    if (!occluded) {
+                        const float cosine1 = absdot(n, sd);
+                        const float cosine2 = absdot(light_normal, -sd);
+                        const f3 local_wi = world_to_local(sd, t, n, b);
+                        const f3 bsdf = bsdf_eval(P, sf, local_wo, local_wi);
+                        const float G = cosine2 / (light_distance * light_distance);
+                        if (INTEGRATOR == HJR_INTEGRATOR_NEE_) {
+                            ps.L = ps.L + (ps.thr * ((bsdf * G * cosine1) / light_pdf)) * light_color; // rt.h:258
+                        } else {
+                            const float pt_pdf = bsdf_pdf(sf, local_wo, local_wi) * G;
+                            const float mis_weight = light_pdf / (light_pdf + pt_pdf);
+                            ps.L = ps.L + ((ps.thr * ((bsdf * G * cosine1) / light_pdf)) * mis_weight) * light_color; // rt.h:378
+                        }
+                    }
+                }
+
+                if (INTEGRATOR == HJR_INTEGRATOR_MIS_) { // BSDF-sampled light hit, rt.h:383-420
+                    float pt_pdf = 1.0f; // uninitialised in the reference when msGGX returns early; defined as 1
+                    f3 local_wi = V(0.0f, 1.0f, 0.0f);
+                    const f3 brdf = bsdf_sample(P, sf, local_wo, local_wi, pt_pdf, ps.st);
+                    const f3 wi = local_to_world(local_wi, t, n, b);
+                    const float cosine1 = absdot(wi, n);
+                    HitInfo lh;
+                    ray_trace<STATS, HJR_BLOCK>(P, prd.position, wi, lh, stack, lc);
+                    if (lh.is_hit) {
+                        if (lh.is_light) {
+                            const float cosine2 = absdot(-wi, lh.normal);
+                            const float light_distance = length3(lh.position - prd.position);
+                            const float invG = light_distance * light_distance / cosine2;
+                            // getLightPDF(prim, inst) (light_sample.h:77-92): 1 / (area * light_prim_count), area from the light
+                            // table's world vertices (== transform_position of the same object vertices); the table row of an
+                            // emissive triangle is found by its global prim id (l4.w)
+                            float lp = 0.0f;
+                            if (!sf.is_specular) {
+                                for (uint32_t li = 0; li < P.n_lights; li++) {
+                                    const float4* Lr = P.lights + (size_t)li * HJR_LIGHT_F4;
+                                    if (f2bits(Lr[4].w) == lh.prim) {
+                                        const float4 a0 = Lr[0], a1 = Lr[1], a2 = Lr[2];
+                                        const f3 c = cross(V(a1.x, a1.y, a1.z) - V(a0.x, a0.y, a0.z), V(a2.x, a2.y, a2.z) - V(a0.x, a0.y, a0.z));
+                                        const float area = length3(c) * 0.5f;
+                                        lp = 1.0f / (area * P.n_lights);
+                                        break;
+                                    }
+                                }
+                                lp = lp * invG;
+                            }
+                            const float mis_weight = pt_pdf / (pt_pdf + lp);
+                            ps.L = ps.L + ((((ps.thr * mis_weight) * cosine1) * lh.emission) * brdf) / pt_pdf; // rt.h:414
+                        }
+                    } else {
+                        ps.L = ps.L + (((ps.thr * brdf) * cosine1) * lh.emission) / pt_pdf; // rt.h:418
+                    }
+                }
+
+                float pdf = 1.0f;
+                f3 local_wi = V(0.0f, 1.0f, 0.0f);
+                if (INTEGRATOR != HJR_INTEGRATOR_PT_) (void)cmj_2d(ps.st); // drawn and discarded by the reference (rt.h:266, 426)
+                const f3 bsdf = bsdf_sample(P, sf, local_wo, local_wi, pdf, ps.st);
+                const f3 wi = local_to_world(local_wi, t, n, b);
+                ps.thr = ps.thr * ((bsdf * fabsf(dot(wi, n))) / pdf); // rt.h:274
+                ps.ro = prd.position;
+                ps.rd = wi;
+                ps.depth++;
+                if (ps.depth == 10) end_path(); // MaxDepth (rt.h:166)
+            }
+        }
+    }
+
+    if (STATS) {
+        for (int i = 0; i < HJR_NSTAT; i++) {
+            unsigned long long v = lc[i];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+            if (lane == 0 && v) atomicAdd(&P.stats[i], v);
+        }
+    }
+}

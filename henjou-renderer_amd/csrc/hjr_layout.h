@@ -1,0 +1,30 @@
+// Device data layout shared by the host-side frame builder and the HIP kernel.
+// Everything is 16-byte records so that each per-lane fetch is a global_load_dwordx4.
+#pragma once
+#include <stdint.h>
+
+#define HJR_TILE 8u                 /* 8x8 pixel tiles = one wavefront of pixels */
+#define HJR_STACK_DEPTH 32          /* per-lane traversal stack entries (LDS); the builder caps tree depth at this */
+#define HJR_LEAF_FLAG 0x80000000u   /* child ref: bit31 = leaf, bits 27..30 = triangle count, bits 0..26 = first triangle */
+#define HJR_LEAF_MAX 4u
+#define HJR_MAX_TRIS (1u << 27)
+
+/* BVH2 node, 64 B = 4 x float4; holds the (padded) boxes of both children.
+ *   q0 = (lo0.x lo0.y lo0.z hi0.x)  q1 = (hi0.y hi0.z lo1.x lo1.y)  q2 = (lo1.z hi1.x hi1.y hi1.z)
+ *   q3 = (child0, child1, 0, 0) as uint bits */
+#define HJR_NODE_F4 4
+/* Triangle (leaf order), 48 B = 3 x float4: world-space vertices + global prim id.
+ *   g0 = (v0.x v0.y v0.z v1.x)  g1 = (v1.y v1.z v2.x v2.y)  g2 = (v2.z, prim_id bits, 0, 0) */
+#define HJR_TRI_F4 3
+/* Shading record by GLOBAL prim id, 64 B = 4 x float4: world normals (each normalised, __closesthit__ch) + uvs + material.
+ *   s0 = (n0.xyz uv0.x) s1 = (n1.xyz uv0.y) s2 = (n2.xyz uv1.x) s3 = (uv1.y uv2.x uv2.y material_id bits) */
+#define HJR_SHADE_F4 4
+/* Material, 64 B = hjr_material verbatim (include/henjou_hip.h). */
+#define HJR_MAT_F4 4
+/* Light triangle, 96 B = 6 x float4 (light_sample.h:43-72 hoisted to once per frame):
+ *   l0 = (v0.xyz pdf)  l1 = (v1.xyz em.x)  l2 = (v2.xyz em.y)  l3 = (n0.xyz em.z)  l4 = (n1.xyz 0)  l5 = (n2.xyz 0)
+ *   v*: transform_position(transforms[inst]); n*: transform_normal(inv_transforms[inst]) (NOT normalised);
+ *   pdf = float(1.0 / area) * (1.0f / light_prim_count) */
+#define HJR_LIGHT_F4 6
+
+#define HJR_NSTAT 10 /* order of hjr_stats' uint64 counters */

@@ -1,0 +1,200 @@
+// Host half of the C-ABI (include/henjou_hip.h): scene surface, output stage and the whole-file driver
+// hjr_render_file == Renderer::initializeAndRender (renderer/renderer.h:1053-1317).
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/henjou_hip.h"
+#include "scene.hpp"
+
+namespace hjr {
+static thread_local std::string g_err;
+void set_error(const std::string& s) { g_err = s; }
+bool write_png(const std::string& path, const uint8_t* rgba, uint32_t w, uint32_t h, bool flip_y, std::string& err);
+bool read_png_rgba8(const std::string& path, std::vector<uint8_t>& rgba, int& w, int& h, std::string& err);
+bool write_pfm(const std::string& path, const float* rgba, uint32_t w, uint32_t h, std::string& err);
+void float4_to_srgb8(const float* rgba, uint8_t* out, uint32_t n);
+} // namespace hjr
+using hjr::set_error;
+
+struct hjr_scene {
+    hjr::SceneData data;
+};
+
+extern "C" const char* hjr_last_error(void) { return hjr::g_err.c_str(); }
+
+extern "C" int hjr_load_render_option(const char* json_path, hjr_render_option* out)
+{
+    if (!json_path || !out) { set_error("hjr_load_render_option: null argument"); return HJR_ERR_ARG; }
+    std::string err;
+    if (!hjr::load_render_option(json_path, *out, err)) {
+        set_error(err);
+        return err.rfind("File ", 0) == 0 ? HJR_ERR_IO : HJR_ERR_PARSE;
+    }
+    return HJR_OK;
+}
+
+extern "C" int hjr_scene_load_gltf(const char* dir, const char* file, hjr_render_option* opt, hjr_scene** out)
+{
+    if (!dir || !file || !opt || !out) { set_error("hjr_scene_load_gltf: null argument"); return HJR_ERR_ARG; }
+    *out = nullptr;
+    hjr_scene* s = new hjr_scene();
+    std::string err;
+    if (!hjr::load_gltf(dir, file, s->data, *opt, err)) {
+        set_error(err);
+        delete s;
+        return err.find("cannot open") != std::string::npos ? HJR_ERR_IO : HJR_ERR_PARSE;
+    }
+    *out = s;
+    return HJR_OK;
+}
+
+extern "C" void hjr_scene_free(hjr_scene* s) { delete s; }
+
+extern "C" int hjr_scene_get_view(const hjr_scene* s, hjr_scene_view* v)
+{
+    if (!s || !v) { set_error("hjr_scene_get_view: null argument"); return HJR_ERR_ARG; }
+    const hjr::SceneData& d = s->data;
+    memset(v, 0, sizeof(*v));
+    v->n_vertices = (uint32_t)d.vertices.size();
+    v->n_triangles = (uint32_t)(d.indices.size() / 3);
+    v->n_instances = (uint32_t)d.instances.size();
+    v->n_materials = (uint32_t)d.materials.size();
+    v->n_lights = (uint32_t)d.light_prim_ids.size();
+    v->n_animations = (uint32_t)d.animations.size();
+    v->vertices = d.vertices.empty() ? nullptr : &d.vertices[0].x;
+    v->normals = d.normals.empty() ? nullptr : &d.normals[0].x;
+    v->texcoords = d.texcoords.empty() ? nullptr : &d.texcoords[0].x;
+    v->indices = d.indices.data();
+    v->material_ids = d.material_ids.data();
+    v->prim_offset = d.prim_offset.data();
+    v->geometry_index_offset = d.geo_index_offset.data();
+    v->geometry_index_count = d.geo_index_count.data();
+    v->instance_animation_id = d.inst_animation_id.data();
+    v->materials = d.materials.data();
+    v->light_prim_ids = d.light_prim_ids.data();
+    v->light_prim_emission = d.light_prim_emission.empty() ? nullptr : &d.light_prim_emission[0].x;
+    return HJR_OK;
+}
+
+extern "C" int hjr_scene_eval_transforms(const hjr_scene* s, float time, float* m12, float* inv12)
+{
+    if (!s || ((!m12 || !inv12) && !s->data.instances.empty())) { set_error("hjr_scene_eval_transforms: null argument"); return HJR_ERR_ARG; }
+    hjr::eval_transforms(s->data, time, m12, inv12);
+    return HJR_OK;
+}
+
+extern "C" int hjr_scene_eval_camera(const hjr_scene* s, const hjr_render_option* opt, float time, hjr_camera* out)
+{
+    if (!s || !opt || !out) { set_error("hjr_scene_eval_camera: null argument"); return HJR_ERR_ARG; }
+    hjr::eval_camera(s->data, *opt, time, *out);
+    return HJR_OK;
+}
+
+extern "C" int hjr_load_png_rgba8(const char* path, uint8_t** rgba, int* w, int* h)
+{
+    if (!path || !rgba || !w || !h) { set_error("hjr_load_png_rgba8: null argument"); return HJR_ERR_ARG; }
+    std::vector<uint8_t> px;
+    std::string err;
+    if (!hjr::read_png_rgba8(path, px, *w, *h, err)) {
+        set_error(err);
+        return err.rfind("cannot open", 0) == 0 ? HJR_ERR_IO : HJR_ERR_PARSE;
+    }
+    *rgba = (uint8_t*)malloc(px.size());
+    if (!*rgba) { set_error("out of memory"); return HJR_ERR_ARG; }
+    memcpy(*rgba, px.data(), px.size());
+    return HJR_OK;
+}
+
+extern "C" void hjr_free(void* p) { free(p); }
+
+extern "C" int hjr_float4_to_srgb8(const float* rgba, uint8_t* out, uint32_t n)
+{
+    if ((!rgba || !out) && n) { set_error("hjr_float4_to_srgb8: null argument"); return HJR_ERR_ARG; }
+    hjr::float4_to_srgb8(rgba, out, n);
+    return HJR_OK;
+}
+
+extern "C" int hjr_write_png(const char* path, const uint8_t* rgba8, uint32_t w, uint32_t h, int flip_y)
+{
+    if (!path || !rgba8) { set_error("hjr_write_png: null argument"); return HJR_ERR_ARG; }
+    std::string err;
+    if (!hjr::write_png(path, rgba8, w, h, flip_y != 0, err)) { set_error(err); return HJR_ERR_IO; }
+    return HJR_OK;
+}
+
+extern "C" int hjr_write_pfm(const char* path, const float* rgba, uint32_t w, uint32_t h)
+{
+    if (!path || !rgba) { set_error("hjr_write_pfm: null argument"); return HJR_ERR_ARG; }
+    std::string err;
+    if (!hjr::write_pfm(path, rgba, w, h, err)) { set_error(err); return HJR_ERR_IO; }
+    return HJR_OK;
+}
+
+// Renderer::initializeAndRender — renderer/renderer.h:1053-1317.  Only Render_mode "Default" is in scope: the denoise
+// modes need the OptiX AI denoiser (renderer/denoiser.h), which in Default mode is an identity pass (blendFactor 1).
+extern "C" int hjr_render_file(const char* render_option_json, int device)
+{
+    if (!render_option_json) { set_error("hjr_render_file: null path"); return HJR_ERR_ARG; }
+    hjr_render_option opt;
+    int rc = hjr_load_render_option(render_option_json, &opt);
+    if (rc != HJR_OK) return rc;
+    if (opt.render_mode != HJR_MODE_DEFAULT) { set_error("hjr_render_file: only Render_mode \"Default\" is supported (no OptiX denoiser on this platform)"); return HJR_ERR_ARG; }
+    if (opt.use_IBL) { set_error("hjr_render_file: use_IBL=true (equirect HDR sky) is not implemented yet; the constant scene_sky_default sky is"); return HJR_ERR_ARG; }
+    hjr_scene* scene = nullptr;
+    rc = hjr_scene_load_gltf(opt.gltf_path, opt.gltf_name, &opt, &scene);
+    if (rc != HJR_OK) return rc;
+    hjr_ctx* ctx = nullptr;
+    rc = hjr_create(device, &ctx);
+    if (rc != HJR_OK) { hjr_scene_free(scene); return rc; }
+    hjr_scene_view view;
+    hjr_scene_get_view(scene, &view);
+    rc = hjr_upload_scene(ctx, &view);
+    if (rc == HJR_OK) { // setLUT (renderer.h:854-898); a missing LUT file only matters if a material uses it
+        uint8_t* lut = nullptr;
+        int lw = 0, lh = 0;
+        if (hjr_load_png_rgba8(opt.LUT_path, &lut, &lw, &lh) == HJR_OK) {
+            rc = hjr_set_lut(ctx, lut, lw, lh);
+            hjr_free(lut);
+        } else {
+            bool needs = false;
+            for (uint32_t i = 0; i < view.n_materials; i++) needs = needs || view.materials[i].is_thinfilm;
+            if (needs) rc = HJR_ERR_IO; // hjr_last_error() already holds the PNG error
+        }
+    }
+    std::vector<float> m((size_t)view.n_instances * 12), inv((size_t)view.n_instances * 12);
+    const size_t npx = (size_t)opt.image_width * opt.image_height;
+    std::vector<float> color(npx * 4), albedo(npx * 4), normal(npx * 4);
+    std::vector<uint8_t> rgba8(npx * 4);
+    for (uint32_t frame = opt.start_frame; rc == HJR_OK && frame < opt.end_frame; frame++) {
+        float time = frame / float(opt.fps); // renderer.h:1128
+        hjr_scene_eval_transforms(scene, time, m.data(), inv.data());
+        rc = hjr_set_transforms(ctx, m.data(), inv.data(), view.n_instances);
+        if (rc != HJR_OK) break;
+        hjr_params p;
+        memset(&p, 0, sizeof(p));
+        p.width = opt.image_width; p.height = opt.image_height;
+        p.spp = opt.max_spp; p.frame = frame; p.seed = opt.seed; p.integrator = (uint32_t)opt.integrator;
+        hjr_scene_eval_camera(scene, &opt, time, &p.camera);
+        for (int k = 0; k < 3; k++) p.sky[k] = opt.scene_sky_default[k];
+        p.ibl_intensity = opt.IBL_intensity;
+        p.rank = 0; p.world_size = 1;
+        rc = hjr_render(ctx, &p, color.data(), albedo.data(), normal.data());
+        if (rc != HJR_OK) break;
+        hjr_stats st;
+        if (hjr_get_stats(ctx, &st) == HJR_OK)
+            fprintf(stderr, "[henjou] frame %u: %ux%u, %u spp, kernel %.3f ms (%.2f Msamples/s)\n", frame, p.width, p.height, p.spp,
+                    st.last_kernel_ms, st.last_kernel_ms > 0 ? (double)npx * p.spp / (st.last_kernel_ms * 1e3) : 0.0);
+        hjr_float4_to_srgb8(color.data(), rgba8.data(), (uint32_t)npx);
+        std::string str_frame = std::to_string(frame); // renderer.h:1291-1302
+        if (str_frame.size() < 2) str_frame = "00" + str_frame;
+        else if (str_frame.size() < 3) str_frame = "0" + str_frame;
+        std::string imagename = std::string(opt.image_name) + "_" + str_frame + ".png";
+        rc = hjr_write_png(imagename.c_str(), rgba8.data(), opt.image_width, opt.image_height, 1);
+    }
+    hjr_destroy(ctx);
+    hjr_scene_free(scene);
+    return rc;
+}

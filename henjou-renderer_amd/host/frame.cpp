@@ -1,0 +1,291 @@
+#include "frame.hpp"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <string>
+
+namespace hjr {
+
+bool SceneCopy::set(const hjr_scene_view& v, std::string& err)
+{
+    if (v.n_triangles >= HJR_MAX_TRIS) { err = "too many triangles"; return false; }
+    if (v.n_triangles && (!v.vertices || !v.normals || !v.texcoords || !v.indices || !v.material_ids)) { err = "null geometry pointer"; return false; }
+    if (v.n_instances && !v.prim_offset) { err = "null prim_offset"; return false; }
+    if (v.n_materials && !v.materials) { err = "null materials"; return false; }
+    if (v.n_lights && (!v.light_prim_ids || !v.light_prim_emission)) { err = "null light arrays"; return false; }
+    if (v.n_triangles && v.n_instances == 0) { err = "triangles without instances"; return false; }
+    n_triangles = v.n_triangles;
+    n_instances = v.n_instances;
+    vertices.assign(v.vertices, v.vertices + 3 * (size_t)v.n_vertices);
+    normals.assign(v.normals, v.normals + 3 * (size_t)v.n_vertices);
+    texcoords.assign(v.texcoords, v.texcoords + 2 * (size_t)v.n_vertices);
+    indices.assign(v.indices, v.indices + 3 * (size_t)v.n_triangles);
+    material_ids.assign(v.material_ids, v.material_ids + v.n_triangles);
+    prim_offset.assign(v.prim_offset, v.prim_offset + v.n_instances);
+    materials.assign(v.materials, v.materials + v.n_materials);
+    light_prim_ids.assign(v.light_prim_ids, v.light_prim_ids + v.n_lights);
+    light_prim_emission.assign(v.light_prim_emission, v.light_prim_emission + 3 * (size_t)v.n_lights);
+    for (uint32_t i = 0; i < 3 * v.n_triangles; i++)
+        if (indices[i] >= v.n_vertices) { err = "vertex index out of range"; return false; }
+    for (uint32_t t = 0; t < v.n_triangles; t++)
+        if (material_ids[t] >= v.n_materials) { err = "material id out of range"; return false; }
+    for (uint32_t i = 0; i < v.n_instances; i++)
+        if (prim_offset[i] > v.n_triangles || (i && prim_offset[i] < prim_offset[i - 1])) { err = "prim_offset not ascending"; return false; }
+    if (v.n_instances && prim_offset[0] != 0) { err = "prim_offset[0] must be 0"; return false; }
+    for (uint32_t l = 0; l < v.n_lights; l++)
+        if (light_prim_ids[l] >= v.n_triangles) { err = "light prim id out of range"; return false; }
+    return true;
+}
+
+namespace {
+
+struct V3 { float x, y, z; };
+inline V3 sub(V3 a, V3 b) { return { a.x - b.x, a.y - b.y, a.z - b.z }; }
+inline float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline V3 cross(V3 a, V3 b) { return { a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x }; }
+// kernel/math.h:73-87 with sutil's dot(float4,float4) = x+y+z+w terms left to right
+inline V3 transform_position(const float* m, V3 p)
+{
+    return { m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3] * 1.0f, m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7] * 1.0f,
+             m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11] * 1.0f };
+}
+inline V3 transform_normal(const float* m, V3 n)
+{
+    return { m[0] * n.x + m[4] * n.y + m[8] * n.z + 0.0f * 0.0f, m[1] * n.x + m[5] * n.y + m[9] * n.z + 0.0f * 0.0f,
+             m[2] * n.x + m[6] * n.y + m[10] * n.z + 0.0f * 0.0f };
+}
+inline V3 normalize(V3 v)
+{
+    float inv = 1.0f / sqrtf(dot(v, v));
+    return { v.x * inv, v.y * inv, v.z * inv };
+}
+inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+struct Box {
+    float lo[3], hi[3];
+    void reset() { for (int a = 0; a < 3; a++) { lo[a] = FLT_MAX; hi[a] = -FLT_MAX; } }
+    void grow(const Box& b) { for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], b.lo[a]); hi[a] = std::max(hi[a], b.hi[a]); } }
+    void grow(const float* p) { for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], p[a]); hi[a] = std::max(hi[a], p[a]); } }
+    float area() const
+    {
+        float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        return (dx < 0) ? 0.0f : 2.0f * (dx * dy + dy * dz + dz * dx);
+    }
+};
+
+struct BuildNode { Box box; int left = -1, right = -1; uint32_t first = 0, count = 0; };
+
+struct Builder {
+    std::vector<Box> tbox;
+    std::vector<float> cent; // 3 per tri
+    std::vector<uint32_t> order;
+    std::vector<BuildNode> nodes;
+    uint32_t max_depth = 0;
+
+    int build(uint32_t first, uint32_t count, uint32_t depth)
+    {
+        int me = (int)nodes.size();
+        nodes.emplace_back();
+        Box bb, cb;
+        bb.reset(); cb.reset();
+        for (uint32_t i = first; i < first + count; i++) { bb.grow(tbox[order[i]]); cb.grow(&cent[3 * order[i]]); }
+        nodes[me].box = bb;
+        max_depth = std::max(max_depth, depth);
+        if (count <= HJR_LEAF_MAX && (count <= 1 || depth > 0)) { // the root is always split so that it is an inner node
+            nodes[me].first = first; nodes[me].count = count;
+            return me;
+        }
+        // depth budget: with `levels` levels left a balanced tree must still fit
+        uint32_t need = 0;
+        while ((HJR_LEAF_MAX << need) < count) need++;
+        bool force_median = depth + need + 1 >= HJR_STACK_DEPTH;
+        uint32_t mid = first;
+        bool have = false;
+        if (!force_median) {
+            const int NB = 16;
+            float best = FLT_MAX; int bax = -1, bsp = -1;
+            for (int ax = 0; ax < 3; ax++) {
+                float c0 = cb.lo[ax], c1 = cb.hi[ax];
+                if (!(c1 > c0)) continue;
+                Box bins[NB]; uint32_t cnt[NB];
+                for (int b = 0; b < NB; b++) { bins[b].reset(); cnt[b] = 0; }
+                float scale = (float)NB / (c1 - c0);
+                for (uint32_t i = first; i < first + count; i++) {
+                    int b = (int)((cent[3 * order[i] + ax] - c0) * scale);
+                    b = b < 0 ? 0 : (b >= NB ? NB - 1 : b);
+                    bins[b].grow(tbox[order[i]]); cnt[b]++;
+                }
+                float rarea[NB]; uint32_t rcnt[NB];
+                Box acc; acc.reset(); uint32_t n = 0;
+                for (int b = NB - 1; b > 0; b--) { acc.grow(bins[b]); n += cnt[b]; rarea[b] = acc.area(); rcnt[b] = n; }
+                acc.reset(); n = 0;
+                for (int b = 0; b < NB - 1; b++) {
+                    acc.grow(bins[b]); n += cnt[b];
+                    if (n == 0 || rcnt[b + 1] == 0) continue;
+                    float cost = acc.area() * (float)n + rarea[b + 1] * (float)rcnt[b + 1];
+                    if (cost < best) { best = cost; bax = ax; bsp = b; }
+                }
+            }
+            if (bax >= 0) {
+                float c0 = cb.lo[bax], c1 = cb.hi[bax];
+                float scale = 16.0f / (c1 - c0);
+                auto it = std::partition(order.begin() + first, order.begin() + first + count, [&](uint32_t t) {
+                    int b = (int)((cent[3 * t + bax] - c0) * scale);
+                    b = b < 0 ? 0 : (b >= 16 ? 15 : b);
+                    return b <= bsp;
+                });
+                mid = (uint32_t)(it - order.begin());
+                have = mid > first && mid < first + count;
+            }
+        }
+        if (!have) { // median split along the widest centroid axis (also the depth-budget fallback)
+            int ax = 0;
+            float ext = cb.hi[0] - cb.lo[0];
+            for (int a = 1; a < 3; a++) if (cb.hi[a] - cb.lo[a] > ext) { ext = cb.hi[a] - cb.lo[a]; ax = a; }
+            mid = first + count / 2;
+            std::nth_element(order.begin() + first, order.begin() + mid, order.begin() + first + count,
+                             [&](uint32_t a, uint32_t b) { return cent[3 * a + ax] < cent[3 * b + ax] || (cent[3 * a + ax] == cent[3 * b + ax] && a < b); });
+        }
+        int l = build(first, mid - first, depth + 1);
+        int r = build(mid, first + count - mid, depth + 1);
+        nodes[me].left = l; nodes[me].right = r;
+        return me;
+    }
+};
+
+} // namespace
+
+bool build_frame(const SceneCopy& sc, const float* M, const float* Mi, uint32_t n_inst, FrameData& out, std::string& err)
+{
+    if (n_inst != sc.n_instances) { err = "instance count does not match the uploaded scene"; return false; }
+    const uint32_t n = sc.n_triangles;
+    out = FrameData();
+    out.n_tris = n;
+    out.tri_shade.assign((size_t)n * HJR_SHADE_F4 * 4, 0.0f);
+    out.tri_inst.assign(n, 0);
+    std::vector<float> wv((size_t)n * 9);
+
+    // __closesthit__ch's per-hit work, done once per triangle (stale ptx:900-1263)
+    for (uint32_t i = 0; i < n_inst; i++) {
+        uint32_t t0 = sc.prim_offset[i], t1 = (i + 1 < n_inst) ? sc.prim_offset[i + 1] : n;
+        const float* m = M + 12 * i;
+        const float* mi = Mi + 12 * i;
+        for (uint32_t t = t0; t < t1; t++) {
+            float* s = &out.tri_shade[(size_t)t * 16];
+            float uv[6];
+            for (int k = 0; k < 3; k++) {
+                uint32_t idx = sc.indices[3 * t + k];
+                V3 v = transform_position(m, { sc.vertices[3 * idx], sc.vertices[3 * idx + 1], sc.vertices[3 * idx + 2] });
+                V3 nn = normalize(transform_normal(mi, { sc.normals[3 * idx], sc.normals[3 * idx + 1], sc.normals[3 * idx + 2] }));
+                wv[9 * (size_t)t + 3 * k + 0] = v.x; wv[9 * (size_t)t + 3 * k + 1] = v.y; wv[9 * (size_t)t + 3 * k + 2] = v.z;
+                s[4 * k + 0] = nn.x; s[4 * k + 1] = nn.y; s[4 * k + 2] = nn.z;
+                uv[2 * k] = sc.texcoords[2 * idx]; uv[2 * k + 1] = sc.texcoords[2 * idx + 1];
+            }
+            s[3] = uv[0]; s[7] = uv[1]; s[11] = uv[2];
+            s[12] = uv[3]; s[13] = uv[4]; s[14] = uv[5];
+            s[15] = u2f(sc.material_ids[t]);
+            out.tri_inst[t] = i;
+        }
+    }
+
+    // light table (light_sample.h:22-58, 69-72)
+    const uint32_t nl = (uint32_t)sc.light_prim_ids.size();
+    out.n_lights = nl;
+    out.lights.assign((size_t)nl * HJR_LIGHT_F4 * 4, 0.0f);
+    for (uint32_t l = 0; l < nl; l++) {
+        uint32_t prim = sc.light_prim_ids[l];
+        // the reference's binary search over prim_offsets (light_sample.h:26-38) == last offset <= prim
+        uint32_t inst = (uint32_t)(std::upper_bound(sc.prim_offset.begin(), sc.prim_offset.end(), prim) - sc.prim_offset.begin()) - 1;
+        const float* m = M + 12 * inst;
+        const float* mi = Mi + 12 * inst;
+        V3 v[3], nn[3];
+        for (int k = 0; k < 3; k++) {
+            uint32_t idx = sc.indices[3 * prim + k];
+            v[k] = transform_position(m, { sc.vertices[3 * idx], sc.vertices[3 * idx + 1], sc.vertices[3 * idx + 2] });
+            nn[k] = transform_normal(mi, { sc.normals[3 * idx], sc.normals[3 * idx + 1], sc.normals[3 * idx + 2] });
+        }
+        V3 c = cross(sub(v[1], v[0]), sub(v[2], v[0]));
+        float area = sqrtf(dot(c, c)) * 0.5f;
+        float select_pdf = 1.0f / nl;
+        float pdf = (float)(1.0 / (double)area); // `pdf = 1.0 / light_area;` is a double division (light_sample.h:69)
+        pdf *= select_pdf;
+        float* L = &out.lights[(size_t)l * 24];
+        for (int k = 0; k < 3; k++) {
+            L[4 * k + 0] = v[k].x; L[4 * k + 1] = v[k].y; L[4 * k + 2] = v[k].z;
+            L[12 + 4 * k + 0] = nn[k].x; L[12 + 4 * k + 1] = nn[k].y; L[12 + 4 * k + 2] = nn[k].z;
+        }
+        L[3] = pdf;
+        L[19] = u2f(prim); // l4.w: global prim id (MIS looks the emissive triangle up by it)
+        L[7] = sc.light_prim_emission[3 * l]; L[11] = sc.light_prim_emission[3 * l + 1]; L[15] = sc.light_prim_emission[3 * l + 2];
+    }
+
+    // BVH over padded triangle boxes
+    Builder B;
+    B.tbox.resize(n); B.cent.resize((size_t)n * 3); B.order.resize(n);
+    float smax = 0.0f;
+    for (uint32_t t = 0; t < n; t++) {
+        Box b; b.reset();
+        for (int k = 0; k < 3; k++) b.grow(&wv[9 * (size_t)t + 3 * k]);
+        for (int a = 0; a < 3; a++) {
+            B.cent[3 * (size_t)t + a] = 0.5f * (b.lo[a] + b.hi[a]);
+            smax = std::max(smax, std::max(fabsf(b.lo[a]), fabsf(b.hi[a])));
+        }
+        B.tbox[t] = b; B.order[t] = t;
+    }
+    if (!(smax < 1e30f)) { err = "non-finite vertex after transform"; return false; }
+    // conservative padding: the slab test must never cull a triangle the canonical ray/triangle test accepts
+    float pad = smax * (1.0f / 32768.0f);
+    for (uint32_t t = 0; t < n; t++)
+        for (int a = 0; a < 3; a++) { B.tbox[t].lo[a] -= pad; B.tbox[t].hi[a] += pad; }
+
+    out.tri_geom.assign((size_t)std::max(n, 1u) * HJR_TRI_F4 * 4, 0.0f);
+    auto leaf_ref = [](uint32_t first, uint32_t count) { return HJR_LEAF_FLAG | (count << 27) | first; };
+    if (n == 0) {
+        out.nodes.assign(16, 0.0f);
+        out.nodes[12] = u2f(leaf_ref(0, 0)); out.nodes[13] = u2f(leaf_ref(0, 0));
+        out.n_nodes = 1;
+        return true;
+    }
+    B.nodes.reserve((size_t)2 * n);
+    B.build(0, n, 0);
+    if (B.max_depth >= HJR_STACK_DEPTH) { err = "BVH deeper than the traversal stack"; return false; }
+    out.depth = B.max_depth;
+    for (uint32_t k = 0; k < n; k++) {
+        uint32_t t = B.order[k];
+        float* g = &out.tri_geom[(size_t)k * 12];
+        memcpy(g, &wv[9 * (size_t)t], 9 * sizeof(float));
+        g[9] = u2f(t);
+    }
+    // emit inner nodes depth-first; a root that is itself a leaf (n == 1) gets an empty sibling
+    std::vector<int> inner_id(B.nodes.size(), -1);
+    uint32_t n_inner = 0;
+    for (size_t i = 0; i < B.nodes.size(); i++) if (B.nodes[i].left >= 0) inner_id[i] = (int)n_inner++;
+    if (n_inner == 0) {
+        out.nodes.assign(16, 0.0f);
+        const BuildNode& r = B.nodes[0];
+        float* q = out.nodes.data();
+        q[0] = r.box.lo[0]; q[1] = r.box.lo[1]; q[2] = r.box.lo[2]; q[3] = r.box.hi[0]; q[4] = r.box.hi[1]; q[5] = r.box.hi[2];
+        q[6] = r.box.lo[0]; q[7] = r.box.lo[1]; q[8] = r.box.lo[2]; q[9] = r.box.hi[0]; q[10] = r.box.hi[1]; q[11] = r.box.hi[2];
+        q[12] = u2f(leaf_ref(r.first, r.count)); q[13] = u2f(leaf_ref(0, 0));
+        out.n_nodes = 1;
+        return true;
+    }
+    out.nodes.assign((size_t)n_inner * 16, 0.0f);
+    out.n_nodes = n_inner;
+    for (size_t i = 0; i < B.nodes.size(); i++) {
+        if (inner_id[i] < 0) continue;
+        float* q = &out.nodes[(size_t)inner_id[i] * 16];
+        const BuildNode* ch[2] = { &B.nodes[(size_t)B.nodes[i].left], &B.nodes[(size_t)B.nodes[i].right] };
+        int cid[2] = { B.nodes[i].left, B.nodes[i].right };
+        for (int c = 0; c < 2; c++) {
+            for (int a = 0; a < 3; a++) { q[6 * c + a] = ch[c]->box.lo[a]; q[6 * c + 3 + a] = ch[c]->box.hi[a]; }
+            uint32_t ref = (ch[c]->left >= 0) ? (uint32_t)inner_id[(size_t)cid[c]] : leaf_ref(ch[c]->first, ch[c]->count);
+            q[12 + c] = u2f(ref);
+        }
+    }
+    return true;
+}
+
+} // namespace hjr

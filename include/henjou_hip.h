@@ -1,0 +1,180 @@
+/*
+ * henjou_hip.h — C-ABI of libhenjou_hip.so, the MI355X-native replacement for Henjou-Renderer's
+ * per-pixel-sample hot path (ray generation -> BVH traversal -> BSDF -> NEE integrator).
+ *
+ * Plain C, no exceptions across the boundary, no torch / STL types in any signature.
+ * Every entry point cites the reference interface it replaces (paths relative to the reference's
+ * include/ directory).  Status codes: 0 = ok, negative = error; hjr_last_error() gives the text.
+ *
+ * The reference's in-process boundary is
+ *     cudaMemcpy(d_param, &params) ; optixLaunch(pipeline, stream, d_param, sizeof(Params), &sbt, W, H, 1)
+ * (renderer/renderer.h:1229-1242) against six OptiX programs that read `Params` (kernel/Payload.h:8-10)
+ * and per-material HitGroupData records (renderer/renderer.h:647-738).  Its file-level surface is
+ * render_option.json + a glTF scene in, <image_name>_<frame>.png out (renderer/renderer.h:1053-1317).
+ * Both levels are exported here.
+ */
+#ifndef HENJOU_HIP_H
+#define HENJOU_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HJR_OK 0
+#define HJR_ERR_ARG (-1)     /* bad argument / null pointer / size mismatch */
+#define HJR_ERR_IO (-2)      /* file missing or unreadable */
+#define HJR_ERR_PARSE (-3)   /* malformed JSON / glTF / PNG, or a mandatory key is absent */
+#define HJR_ERR_DEVICE (-4)  /* HIP runtime error, or no gfx950 device / kernel image */
+#define HJR_ERR_STATE (-5)   /* call order violated (render before upload, ...) */
+
+enum { HJR_INTEGRATOR_NEE = 0, HJR_INTEGRATOR_PT = 1, HJR_INTEGRATOR_MIS = 2 }; /* kernel/rt.h:162,85,284 */
+enum { HJR_MODE_DEFAULT = 0, HJR_MODE_DENOISE = 1, HJR_MODE_DENOISE_UPSCALE2X = 2, HJR_MODE_DEBUG = 3 }; /* renderer/render_option.h:38-43 */
+
+/* Mirror of HitGroupData (renderer/renderer.h:659-687) as filled from Material (renderer/material.h:10-63).
+ * Texture slots other than base colour are carried for the loader's sake; the kernel ignores them. */
+typedef struct hjr_material {
+    float basecolor[3];
+    float metallic;
+    float roughness;
+    float sheen;
+    float clearcoat;
+    float ior;
+    float transmission;
+    float emission[3];
+    int32_t is_light;
+    int32_t ideal_specular;
+    int32_t is_thinfilm;
+    int32_t basecolor_tex;   /* -1 = none */
+} hjr_material;              /* 64 bytes */
+
+/* Borrowed, read-only view of SceneData (renderer/scene.h:19-36).  The library copies on upload. */
+typedef struct hjr_scene_view {
+    uint32_t n_vertices;     /* == 3 * n_triangles on the glTF path (de-indexed, gltfloader.h:1484-1492) */
+    uint32_t n_triangles;
+    uint32_t n_instances;    /* instance i <-> geometry i, 1:1 (gltfloader.h:1507-1512) */
+    uint32_t n_materials;
+    uint32_t n_lights;       /* emissive triangles (gltfloader.h:1496-1500) */
+    uint32_t n_animations;   /* == number of glTF nodes */
+    const float*    vertices;            /* float3 x n_vertices, object space */
+    const float*    normals;             /* float3 x n_vertices */
+    const float*    texcoords;           /* float2 x n_vertices */
+    const uint32_t* indices;             /* 3 x n_triangles */
+    const uint32_t* material_ids;        /* n_triangles */
+    const uint32_t* prim_offset;         /* n_instances: first global triangle of the instance */
+    const uint32_t* geometry_index_offset; /* n_instances (GeometryData.index_offset, scene.h:9-12) */
+    const uint32_t* geometry_index_count;  /* n_instances */
+    const uint32_t* instance_animation_id; /* n_instances (InstanceData.animation_id, scene.h:14-17) */
+    const hjr_material* materials;
+    const uint32_t* light_prim_ids;      /* n_lights, global triangle ids */
+    const float*    light_prim_emission; /* float3 x n_lights */
+} hjr_scene_view;
+
+/* Mirror of RenderOption (renderer/render_option.h:45-84). */
+typedef struct hjr_render_option {
+    uint32_t image_width, image_height;
+    char image_name[256];
+    char image_directory[512];
+    uint32_t max_spp;
+    char gltf_path[512];
+    char gltf_name[256];
+    uint32_t fps, start_frame, end_frame;
+    float time_limit;
+    int32_t allow_camera_animation;
+    float camera_fov;            /* radians after load (render_json_loader.h:144) */
+    float camera_position[3];
+    float camera_direction[3];
+    int32_t camera_animation_id; /* -1 = none */
+    int32_t render_mode;         /* HJR_MODE_* */
+    char ptxfile_path[512];      /* parsed, unused */
+    int32_t use_IBL;
+    char IBL_path[512];
+    float IBL_intensity;
+    float scene_sky_default[3];
+    int32_t use_date, save_renderOption;
+    char LUT_path[512];
+    /* optional "Henjou_HIP" section (ignored by the reference): */
+    uint32_t seed;               /* default 1 */
+    int32_t integrator;          /* default HJR_INTEGRATOR_NEE */
+} hjr_render_option;
+
+typedef struct hjr_camera {      /* Params.camera_* (renderer/renderer.h:1187-1191) */
+    float pos[3], dir[3], up[3], right[3];
+    float f;                     /* camera_f = 2 / tan(fov) (renderer/renderer.h:1147) */
+} hjr_camera;
+
+/* Per-launch parameters: the scalar part of `Params` (renderer/renderer.h:1175-1227). */
+typedef struct hjr_params {
+    uint32_t width, height;      /* params.image_width/height */
+    uint32_t spp;                /* params.spp */
+    uint32_t frame;              /* params.frame */
+    uint32_t seed;               /* CMJState.scramble (build-defined) */
+    uint32_t integrator;         /* HJR_INTEGRATOR_* */
+    hjr_camera camera;
+    float sky[3];                /* scene_sky_default: the 1x1 IBL texel (renderer/texture.h:58-65) */
+    float ibl_intensity;         /* params.ibl_intensity */
+    uint32_t rank, world_size;   /* pixel-tile shard: this launch renders 8x8 tiles t with t % world_size == rank */
+    uint32_t flags;              /* HJR_FLAG_* */
+    uint32_t _reserved;
+} hjr_params;
+#define HJR_FLAG_STATS 1u        /* run the counting variant of the kernel (slower; fills hjr_stats) */
+#define HJR_FLAG_ZERO_UNOWNED 2u /* clear pixels of tiles this rank does not own (for a sum-reduce exchange) */
+
+typedef struct hjr_stats {
+    uint64_t samples, closest_rays, shadow_rays, box_tests_closest, tri_tests_closest,
+             box_tests_shadow, tri_tests_shadow, shaded_hits, light_samples, nan_samples;
+    float    last_kernel_ms;     /* HIP-event time of the last render kernel on its stream */
+    uint32_t bvh_nodes, bvh_depth, n_triangles;
+} hjr_stats;
+
+typedef struct hjr_scene hjr_scene; /* owning, host side (SceneData + animations) */
+typedef struct hjr_ctx hjr_ctx;     /* one per device */
+
+const char* hjr_last_error(void);
+
+/* ---------------- scene surface: the file-level drop-in (host only, no GPU needed) ---------------- */
+/* load_json(filepath, RenderOption&) — loader/render_json_loader.h:78-228 (incl. ./fps.txt override, :164-171) */
+int hjr_load_render_option(const char* json_path, hjr_render_option* out);
+/* gltfloader(filepath, filename, SceneData&, RenderOption&) — loader/gltfloader.h:1068-1601 */
+int hjr_scene_load_gltf(const char* dir, const char* file, hjr_render_option* opt_inout, hjr_scene** out);
+void hjr_scene_free(hjr_scene*);
+int hjr_scene_get_view(const hjr_scene*, hjr_scene_view* out);
+/* Renderer::updateIASMatrix(time) — renderer/renderer.h:257-291: per instance Matrix4x3 + inverse, row-major 3x4 */
+int hjr_scene_eval_transforms(const hjr_scene*, float time, float* transforms12, float* inv_transforms12);
+/* camera block of the frame loop — renderer/renderer.h:1145-1169 */
+int hjr_scene_eval_camera(const hjr_scene*, const hjr_render_option*, float time, hjr_camera* out);
+/* Texture(LUT_path, NonColor) — renderer/texture.h:16-39, loader/texture_load.h:7-20: 8-bit RGBA, caller frees with hjr_free */
+int hjr_load_png_rgba8(const char* path, uint8_t** rgba, int* w, int* h);
+void hjr_free(void*);
+
+/* ---------------- device side: replaces context/GAS/IAS/pipeline/SBT + optixLaunch ---------------- */
+int hjr_create(int device_ordinal, hjr_ctx** out);                 /* optixDeviceContextInitialize, renderer.h:293-312 */
+void hjr_destroy(hjr_ctx*);
+/* cpySceneDataToDevice + optixTraversalBuild(GAS) + optixSBTBuild — renderer.h:197-255, 314-396, 620-739 */
+int hjr_upload_scene(hjr_ctx*, const hjr_scene_view*);
+/* updateIASMatrix + buildIAS — renderer.h:257-291, 398-490.  Flattens to world space and (re)builds the BVH. */
+int hjr_set_transforms(hjr_ctx*, const float* transforms12, const float* inv_transforms12, uint32_t n_instances);
+/* setLUT — renderer.h:854-898 (uchar4, normalised float read, linear, wrap).  NULL clears. */
+int hjr_set_lut(hjr_ctx*, const uint8_t* rgba, int w, int h);
+/* Params fill + optixLaunch + CUDA_SYNC_CHECK + AOV D->H — renderer.h:1175-1242, 103-136.
+ * Host buffers, width*height*4 floats each (albedo/normal may be NULL).  Synchronous. */
+int hjr_render(hjr_ctx*, const hjr_params*, float* aov_color, float* aov_albedo, float* aov_normal);
+/* Same launch writing float4 AOVs straight into caller-owned DEVICE memory (e.g. a torch tensor that then goes
+ * through an RCCL collective), enqueued on `hip_stream` (hipStream_t as void*, NULL = default stream).  Asynchronous. */
+int hjr_render_device(hjr_ctx*, const hjr_params*, void* d_aov_color, void* d_aov_albedo, void* d_aov_normal,
+                      void* hip_stream);
+int hjr_synchronize(hjr_ctx*);
+int hjr_get_stats(hjr_ctx*, hjr_stats* out);
+
+/* ---------------- output stage (host) ---------------- */
+/* float4ConvertColor: toSRGB + quantizeUnsignedChar — renderer/renderer.h:73-101 */
+int hjr_float4_to_srgb8(const float* rgba, uint8_t* out_rgba8, uint32_t n_pixels);
+/* sutil::saveImage(name, buffer, false) — renderer.h:1291-1302.  flip_y != 0 writes row 0 at the bottom. */
+int hjr_write_png(const char* path, const uint8_t* rgba8, uint32_t width, uint32_t height, int flip_y);
+int hjr_write_pfm(const char* path, const float* rgba, uint32_t width, uint32_t height);
+/* Renderer::initializeAndRender(render_option_path) — renderer/renderer.h:1053-1317, whole file-to-PNG path */
+int hjr_render_file(const char* render_option_json, int device_ordinal);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,48 @@
+"""Shared helpers for the tests: loading the bundled scene through the product's loader, oracle params."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as entry  # noqa: E402
+
+hjr = entry.load_package()
+
+
+def f32_time(frame, fps):
+    return float(np.float32(frame) / np.float32(fps))
+
+
+class Cornell:
+    """cornelbox.gltf loaded via libhenjou_hip.so's scene surface, at frame 1 (t = 1/24 s)."""
+
+    def __init__(self, config="render_option_c1.json", gltf=None):
+        cwd = os.getcwd()
+        os.chdir(hjr.ASSETS)
+        try:
+            self.opt = hjr.load_render_option(config)
+            if gltf:
+                self.opt.gltf_name = gltf.encode()
+            self.scene = hjr.Scene(self.opt.gltf_path.decode(), self.opt.gltf_name.decode(), self.opt)
+        finally:
+            os.chdir(cwd)
+        self.time = f32_time(1, self.opt.fps)
+        self.camera = self.scene.camera(self.opt, self.time)
+        self.arrays = self.scene.arrays(self.time)
+
+    def hjr_params(self, w, h, spp, **kw):
+        return hjr.make_params(w, h, spp, self.camera, sky=tuple(self.opt.scene_sky_default),
+                               ibl_intensity=self.opt.IBL_intensity, **kw)
+
+    def oracle_params(self, w, h, spp, **kw):
+        import oracle_binding as ob
+        return ob.make_params(w, h, spp, self.camera.as_dict(), sky=tuple(self.opt.scene_sky_default),
+                              ibl_intensity=self.opt.IBL_intensity, **kw)
+
+    def device(self):
+        d = hjr.Device(0)
+        d.upload_scene(self.scene.view)
+        d.set_transforms(self.arrays["transforms"], self.arrays["inv_transforms"])
+        return d

@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""bench.py — Msamples/s of the Henjou hot path on MI355X (BASELINE.json metric).
+
+A step = one pass of the hot path over one frame: the persistent HIP megakernel renders this rank's 8x8 pixel tiles of
+the BASELINE configs[1] workload (bundled cornelbox.gltf, 1920x1080, 256 spp, NEE integrator, synthetic = the bundled
+scene, no external data), and for N > 1 the float4 framebuffer is summed onto rank 0 with one RCCL reduce over xGMI.
+Scene, BVH and all buffers are resident in HBM before the timed region.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--width 1920 --height 1080 --spp 256]
+    N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+                bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement), plus
+  "roofline":     algorithmic HBM bytes per launch / measured kernel time (HIP events on the kernel's stream) vs 8 TB/s
+  "cpu_baseline": the CPU oracle (a from-scratch port; the reference has no CPU path) timed on the host cores
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes_per_sample(st, spp):
+    """SURVEY.md §8(d) / BASELINE.md §4: bytes the algorithm must touch per sample, from the kernel's own counters.
+    32 B per box test (AABB + link), 36 B per triangle test, 232 B per shaded hit, 192 B per light sample,
+    52 B of AOV write-out per pixel."""
+    n = max(st["samples"], 1)
+    b = (st["box_tests_closest"] * 32 + st["tri_tests_closest"] * 36 + st["box_tests_shadow"] * 32 +
+         st["tri_tests_shadow"] * 36 + st["shaded_hits"] * 232 + st["light_samples"] * 192) / n
+    return b + 52.0 / spp
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=256)
+    ap.add_argument("--integrator", default="NEE", choices=["NEE", "Pathtrace", "MIS"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-spp", type=int, default=4, help="spp of the bounded CPU-baseline sample")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as entry
+    hjr = entry.load_package()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    W, H, SPP = args.width, args.height, args.spp
+    integ = {"NEE": hjr.INTEGRATOR_NEE, "Pathtrace": hjr.INTEGRATOR_PT, "MIS": hjr.INTEGRATOR_MIS}[args.integrator]
+
+    # ---- scene through the drop-in surface (render_option.json + Model/), resident in HBM before timing
+    cwd = os.getcwd()
+    os.chdir(hjr.ASSETS)
+    try:
+        r = hjr.Renderer(local_rank)
+        r.loadRenderOption("render_option_c2.json")
+        r.render_option.image_width, r.render_option.image_height, r.render_option.max_spp = W, H, SPP
+        r.render_option.integrator = integ
+        r.loadGLTFfile(r.render_option.gltf_path.decode(), r.render_option.gltf_name.decode())
+        r.build()
+    finally:
+        os.chdir(cwd)
+    frame = r.render_option.start_frame
+    params, t_frame = r.frame_params(frame, rank=rank, world_size=world,
+                                     flags=hjr.FLAG_ZERO_UNOWNED if world > 1 else 0)
+    m, inv = r.scene.transforms(t_frame)
+    r.device.set_transforms(m, inv)
+
+    fb = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        r.device.render_device(params, fb.data_ptr(), None, None, stream)
+        if world > 1:
+            dist.reduce(fb, dst=0, op=dist.ReduceOp.SUM)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        kernel_ms.append(r.device.stats()["last_kernel_ms"])  # HIP events recorded on the launch stream around the kernel
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    total_samples = float(W) * H * SPP * args.steps
+    value = total_samples / elapsed / 1e6
+    out = {
+        "metric": "Msamples/s at 1920x1080 (path-traced pixel samples per second, whole job)",
+        "value": round(value, 3),
+        "unit": "Msamples/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic (bundled cornelbox.gltf, 984 triangles; CMJ sample streams from a fixed seed)",
+        "config": {"workload": "BASELINE configs[1]: cornelbox.gltf %dx%d %d spp, %s integrator" % (W, H, SPP, args.integrator),
+                   "width": W, "height": H, "spp": SPP, "integrator": args.integrator,
+                   "parallelism": "8x8 pixel tiles round-robin over %d GPU(s)%s" % (world, " + RCCL reduce of the float4 framebuffer" if world > 1 else "")},
+    }
+
+    if rank == 0:
+        # ---- roofline of the dominant (only) kernel: counters from the counting variant at 1/16 of the samples
+        sp = hjr.make_params(W, H, max(SPP // 16, 1), params.camera, frame=params.frame, seed=params.seed, integrator=integ,
+                             sky=tuple(params.sky), ibl_intensity=params.ibl_intensity, rank=rank, world_size=world,
+                             flags=hjr.FLAG_STATS)
+        r.device.render_device(sp, fb.data_ptr(), None, None, stream)
+        torch.cuda.synchronize()
+        st = r.device.stats()
+        bps = algorithmic_bytes_per_sample(st, SPP)
+        samples_per_launch = float(W) * H * SPP / world
+        avg_ms = sum(kernel_ms) / len(kernel_ms)
+        achieved = bps * samples_per_launch / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("%dx%dx%d_%s_n%d" % (W, H, SPP, args.integrator, world))
+            except Exception:
+                traffic = None
+        out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                           "kernel": "hjr_render_kernel<%s>" % args.integrator, "kernel_ms_avg": round(avg_ms, 3),
+                           "algorithmic_bytes_per_sample": round(bps, 1),
+                           "per_sample": {k: round(st[k] / max(st["samples"], 1), 3) for k in
+                                          ("closest_rays", "shadow_rays", "box_tests_closest", "tri_tests_closest",
+                                           "box_tests_shadow", "tri_tests_shadow", "shaded_hits", "light_samples")},
+                           "kernel_Msamples_per_s": round(samples_per_launch / (avg_ms * 1e-3) / 1e6, 3)}
+
+        # ---- CPU baseline: the oracle (kind "port": the reference has no CPU path), bounded sample
+        if world == 1 and not args.no_cpu_baseline:
+            import oracle_binding as ob
+            cores = os.cpu_count() or 1
+            try:
+                cores = len(os.sched_getaffinity(0))
+            except Exception:
+                pass
+            arrays = r.scene.arrays(t_frame)
+            osc = ob.OracleScene(arrays, ob.MATH_LIBM)
+            cspp = max(1, min(args.cpu_spp, SPP))
+            op = ob.make_params(W, H, cspp, params.camera.as_dict(), frame=params.frame, seed=params.seed, integrator=integ,
+                                sky=tuple(params.sky), ibl_intensity=params.ibl_intensity)
+            tc = time.perf_counter()
+            osc.render(op, nthreads=cores, want_aovs=False)
+            dtc = time.perf_counter() - tc
+            out["cpu_baseline"] = {"value": round(W * H * cspp / dtc / 1e6, 4), "unit": "Msamples/s", "cores": cores,
+                                   "kind": "port",
+                                   "sample": "same frame (%dx%d), first %d of %d spp = %.2f Msamples, oracle/hjr_oracle.c in LIBM mode, "
+                                             "%d pthreads over image rows, %.1f s" % (W, H, cspp, SPP, W * H * cspp / 1e6, cores, dtc)}
+        print(json.dumps(out))
+        sys.stdout.flush()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

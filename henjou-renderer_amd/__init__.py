@@ -98,6 +98,13 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise HjrError("libhenjou_hip.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "or `make -C henjou-renderer_amd`; there is no fallback path")
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so (soname libamdhip64.so.7) and asks for
+        # it by file name, so if /opt/rocm's copy were loaded first torch would load a second runtime and then see no GPU.
+        # Importing torch first makes libhenjou_hip.so's NEEDED libamdhip64.so.7 resolve to the copy torch already mapped.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         L.hjr_last_error.restype = C.c_char_p
         for name, args in {

@@ -94,8 +94,7 @@ def main():
 
     def step():
         r.device.render_device(params, fb.data_ptr(), None, None, stream)
-        if world > 1:
-            dist.reduce(fb, dst=0, op=dist.ReduceOp.SUM)
+        hjr.exchange_framebuffer(fb, dst=0)
 
     def fence():
         if world > 1:

@@ -337,6 +337,16 @@ def owned_tile_mask(width, height, rank, world_size, tile=8):
     return ((ty * tiles_x + tx) % world_size) == rank
 
 
+def exchange_framebuffer(fb, dst=0):
+    """The one data-path collective of a multi-GPU frame: every rank holds its own 8x8 tiles and zeros
+    elsewhere; a SUM reduce onto `dst` assembles the frame.  Adding zeros is exact in IEEE arithmetic, so the result is
+    bit-identical to the 1-GPU image.  `fb` is a torch tensor (CUDA -> RCCL over xGMI; CPU -> gloo in the tests)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.reduce(fb, dst=dst, op=dist.ReduceOp.SUM)
+    return fb
+
+
 class Renderer:
     """Mirror of the reference's `class Renderer` (renderer/renderer.h:900-1318) on top of the C-ABI."""
 

@@ -33,13 +33,15 @@ class Cornell:
         self.arrays = self.scene.arrays(self.time)
 
     def hjr_params(self, w, h, spp, **kw):
-        return hjr.make_params(w, h, spp, self.camera, sky=tuple(self.opt.scene_sky_default),
-                               ibl_intensity=self.opt.IBL_intensity, **kw)
+        kw.setdefault("sky", tuple(self.opt.scene_sky_default))
+        kw.setdefault("ibl_intensity", self.opt.IBL_intensity)
+        return hjr.make_params(w, h, spp, self.camera, **kw)
 
     def oracle_params(self, w, h, spp, **kw):
         import oracle_binding as ob
-        return ob.make_params(w, h, spp, self.camera.as_dict(), sky=tuple(self.opt.scene_sky_default),
-                              ibl_intensity=self.opt.IBL_intensity, **kw)
+        kw.setdefault("sky", tuple(self.opt.scene_sky_default))
+        kw.setdefault("ibl_intensity", self.opt.IBL_intensity)
+        return ob.make_params(w, h, spp, self.camera.as_dict(), **kw)
 
     def device(self):
         d = hjr.Device(0)

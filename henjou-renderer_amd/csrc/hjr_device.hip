@@ -3,6 +3,7 @@
 // 1175-1242 Params fill + optixLaunch).  No CPU fallback exists: without a gfx950 device every entry point fails loudly.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -47,9 +48,10 @@ struct hjr_ctx {
     DevBuf d_nodes, d_tri_geom, d_tri_shade, d_tri_inst, d_materials, d_lights, d_lut, d_work;
     int lut_w = 0, lut_h = 0;
     DevBuf d_color, d_albedo, d_normal; // staging for hjr_render (host buffers)
+    DevBuf d_part_color, d_part_albedo, d_part_normal; // chunk sums [n_chunks][H][W] float4
     hjr_stats stats;
     bool event_pending = false;
-    int blocks_per_cu = 4;
+    int blocks_per_cu = 0; // 0 = ask the occupancy API
 };
 
 #define HIPCHK(call)                                                                                            \
@@ -100,7 +102,7 @@ extern "C" void hjr_destroy(hjr_ctx* c)
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     for (DevBuf* b : { &c->d_nodes, &c->d_tri_geom, &c->d_tri_shade, &c->d_tri_inst, &c->d_materials, &c->d_lights, &c->d_lut,
-                       &c->d_work, &c->d_color, &c->d_albedo, &c->d_normal })
+                       &c->d_work, &c->d_color, &c->d_albedo, &c->d_normal, &c->d_part_color, &c->d_part_albedo, &c->d_part_normal })
         b->release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -158,9 +160,17 @@ extern "C" int hjr_set_lut(hjr_ctx* c, const uint8_t* rgba, int w, int h)
     return HJR_OK;
 }
 
-template <int I, bool S> static void launch(const KParams& kp, dim3 grid, hipStream_t st)
+// persistent grid = resident workgroups only: CUs x (workgroups the kernel's VGPR/LDS budget admits per CU), capped by the
+// number of wavefront-sized batches of work; HJR_BLOCKS_PER_CU overrides the occupancy query
+template <int I, bool S> static void launch(const hjr_ctx* c, const KParams& kp, uint64_t max_useful, hipStream_t st)
 {
-    hipLaunchKernelGGL((hjr_render_kernel<I, S>), grid, dim3(HJR_BLOCK), 0, st, kp);
+    int per_cu = 0;
+    if (c->blocks_per_cu > 0) per_cu = c->blocks_per_cu;
+    else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)hjr_render_kernel<I, S>, HJR_BLOCK, 0) != hipSuccess || per_cu < 1)
+        per_cu = 2;
+    uint64_t blocks = (uint64_t)c->n_cus * (uint64_t)per_cu;
+    if (blocks > max_useful) blocks = max_useful;
+    hipLaunchKernelGGL((hjr_render_kernel<I, S>), dim3((unsigned)blocks), dim3(HJR_BLOCK), 0, st, kp);
 }
 
 static int render_impl(hjr_ctx* c, const hjr_params* p, void* d_color, void* d_albedo, void* d_normal, hipStream_t st)
@@ -176,7 +186,9 @@ static int render_impl(hjr_ctx* c, const hjr_params* p, void* d_color, void* d_a
     const uint32_t tiles_x = (p->width + HJR_TILE - 1) / HJR_TILE, tiles_y = (p->height + HJR_TILE - 1) / HJR_TILE;
     const uint64_t n_tiles = (uint64_t)tiles_x * tiles_y;
     const uint64_t owned = (n_tiles > p->rank) ? (n_tiles - p->rank + world - 1) / world : 0;
-    if (owned * 64 >= 0xffffffffull) { set_error("hjr_render: image too large"); return HJR_ERR_ARG; }
+    const uint32_t chunk_spp = hjr_chunk_spp(p->spp), n_chunks = hjr_n_chunks(p->spp);
+    const uint64_t n_items = owned * n_chunks * 64;
+    if (n_items >= 0xffffffffull) { set_error("hjr_render: image too large"); return HJR_ERR_ARG; }
 
     // work area: [0] queue head, [16..] HJR_NSTAT uint64 counters
     const size_t work_bytes = 16 + HJR_NSTAT * 8;
@@ -194,6 +206,23 @@ static int render_impl(hjr_ctx* c, const hjr_params* p, void* d_color, void* d_a
 
     KParams kp;
     memset(&kp, 0, sizeof(kp));
+    if (n_chunks > 1) {
+        const size_t part_bytes = img_bytes * n_chunks;
+        DevBuf* pb[3] = { &c->d_part_color, &c->d_part_albedo, &c->d_part_normal };
+        void* want[3] = { d_color, d_albedo, d_normal };
+        for (int i = 0; i < 3; i++) {
+            if (!want[i]) continue;
+            if (pb[i]->cap < part_bytes) {
+                pb[i]->release();
+                if (hipMalloc(&pb[i]->p, part_bytes) != hipSuccess) { set_error("hjr_render: chunk-sum buffer allocation failed"); return HJR_ERR_DEVICE; }
+                pb[i]->cap = part_bytes;
+            }
+        }
+        kp.part_color = (float4*)c->d_part_color.p;
+        kp.part_albedo = d_albedo ? (float4*)c->d_part_albedo.p : nullptr;
+        kp.part_normal = d_normal ? (float4*)c->d_part_normal.p : nullptr;
+    }
+    kp.chunk_spp = chunk_spp; kp.n_chunks = n_chunks;
     kp.nodes = (const float4*)c->d_nodes.p;
     kp.tri_geom = (const float4*)c->d_tri_geom.p;
     kp.tri_shade = (const float4*)c->d_tri_shade.p;
@@ -207,7 +236,7 @@ static int render_impl(hjr_ctx* c, const hjr_params* p, void* d_color, void* d_a
     kp.stats = (unsigned long long*)((char*)c->d_work.p + 16);
     kp.n_lights = c->frame.n_lights;
     kp.width = p->width; kp.height = p->height; kp.spp = p->spp; kp.frame = p->frame; kp.seed = p->seed; kp.integrator = p->integrator;
-    kp.tiles_x = tiles_x; kp.n_owned_items = (uint32_t)(owned * 64);
+    kp.tiles_x = tiles_x; kp.n_owned_items = (uint32_t)n_items;
     kp.rank = p->rank; kp.world = world;
     for (int k = 0; k < 3; k++) {
         kp.cam_pos[k] = p->camera.pos[k]; kp.cam_dir[k] = p->camera.dir[k];
@@ -216,24 +245,26 @@ static int render_impl(hjr_ctx* c, const hjr_params* p, void* d_color, void* d_a
     }
     kp.cam_f = p->camera.f;
 
-    // persistent grid: blocks_per_cu x #CU workgroups of 4 wavefronts; never more wavefronts than there are pixels to hand out
-    uint64_t want_blocks = (uint64_t)c->n_cus * (uint64_t)c->blocks_per_cu;
-    uint64_t max_useful = (owned * 64 + HJR_BLOCK - 1) / HJR_BLOCK;
+    uint64_t max_useful = (n_items + HJR_BLOCK - 1) / HJR_BLOCK;
     if (max_useful < 1) max_useful = 1;
-    if (want_blocks > max_useful) want_blocks = max_useful;
-    dim3 grid((unsigned)want_blocks);
     const bool stats = (p->flags & HJR_FLAG_STATS) != 0;
 
     HIPCHK(hipEventRecord(c->ev0, st));
     switch (p->integrator * 2 + (stats ? 1 : 0)) {
-    case 0: launch<HJR_INTEGRATOR_NEE, false>(kp, grid, st); break;
-    case 1: launch<HJR_INTEGRATOR_NEE, true>(kp, grid, st); break;
-    case 2: launch<HJR_INTEGRATOR_PT, false>(kp, grid, st); break;
-    case 3: launch<HJR_INTEGRATOR_PT, true>(kp, grid, st); break;
-    case 4: launch<HJR_INTEGRATOR_MIS, false>(kp, grid, st); break;
-    default: launch<HJR_INTEGRATOR_MIS, true>(kp, grid, st); break;
+    case 0: launch<HJR_INTEGRATOR_NEE, false>(c, kp, max_useful, st); break;
+    case 1: launch<HJR_INTEGRATOR_NEE, true>(c, kp, max_useful, st); break;
+    case 2: launch<HJR_INTEGRATOR_PT, false>(c, kp, max_useful, st); break;
+    case 3: launch<HJR_INTEGRATOR_PT, true>(c, kp, max_useful, st); break;
+    case 4: launch<HJR_INTEGRATOR_MIS, false>(c, kp, max_useful, st); break;
+    default: launch<HJR_INTEGRATOR_MIS, true>(c, kp, max_useful, st); break;
     }
     HIPCHK(hipGetLastError());
+    if (n_chunks > 1) {
+        const size_t npix = (size_t)p->width * p->height;
+        unsigned fb = (unsigned)std::min<size_t>((npix + 255) / 256, (size_t)c->n_cus * 8);
+        hipLaunchKernelGGL(hjr_finalize_kernel, dim3(fb), dim3(256), 0, st, kp);
+        HIPCHK(hipGetLastError());
+    }
     HIPCHK(hipEventRecord(c->ev1, st));
     c->event_pending = true;
     return HJR_OK;

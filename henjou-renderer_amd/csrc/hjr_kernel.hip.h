@@ -33,8 +33,12 @@ struct KParams {
     int lut_w, lut_h;
     uint32_t n_lights;
     uint32_t width, height, spp, frame, seed, integrator;
-    uint32_t tiles_x, n_owned_items; // items = owned tiles * 64
+    uint32_t tiles_x, n_owned_items; // items = owned tiles * n_chunks * 64
     uint32_t rank, world;
+    uint32_t chunk_spp, n_chunks;    // samples per work item, work items per pixel (hjr_chunking)
+    float4* part_color;              // [n_chunks][height][width] chunk sums when n_chunks > 1
+    float4* part_albedo;
+    float4* part_normal;
     float cam_pos[3], cam_dir[3], cam_up[3], cam_right[3];
     float cam_f;
     float sky[3]; // scene_sky_default * ibl_intensity
@@ -661,7 +665,7 @@ __global__ void __launch_bounds__(HJR_BLOCK) hjr_render_kernel(const KParams P)
     if (STATS) for (int i = 0; i < HJR_NSTAT; i++) lc[i] = 0;
 
     bool has_pixel = false, dead = false, path_live = false;
-    uint32_t px = 0, py = 0, s = 0;
+    uint32_t px = 0, py = 0, s = 0, s_end = 0, chunk = 0;
     f3 sumL = V1(0.0f), sumA = V1(0.0f), sumN = V1(0.0f);
     PathState ps;
     ps.ro = ps.rd = ps.thr = ps.L = V1(0.0f);
@@ -684,12 +688,18 @@ __global__ void __launch_bounds__(HJR_BLOCK) hjr_render_kernel(const KParams P)
                 if (need) {
                     const uint32_t q = base + prefix;
                     if (q < P.n_owned_items) {
-                        const uint32_t tile = (q >> 6) * P.world + P.rank;
+                        // item q = ((owned tile * n_chunks) + chunk) * 64 + pixel-in-tile: the 64 lanes of a wave start on one
+                        // tile and one sample chunk (coherent primary rays)
+                        const uint32_t tc = q >> 6;
+                        const uint32_t tile = (tc / P.n_chunks) * P.world + P.rank;
+                        chunk = tc % P.n_chunks;
                         const uint32_t tx = tile % P.tiles_x, ty = tile / P.tiles_x;
                         px = tx * HJR_TILE + (q & 7u);
                         py = ty * HJR_TILE + ((q >> 3) & 7u);
                         if (px < P.width && py < P.height) {
-                            has_pixel = true; path_live = false; s = 0;
+                            has_pixel = true; path_live = false;
+                            s = chunk * P.chunk_spp;
+                            s_end = min(s + P.chunk_spp, P.spp);
                             sumL = V1(0.0f); sumA = V1(0.0f); sumN = V1(0.0f);
                         }
                     } else dead = true;
@@ -706,11 +716,18 @@ __global__ void __launch_bounds__(HJR_BLOCK) hjr_render_kernel(const KParams P)
             if (STATS) lc[0] += 1;
             s++;
             path_live = false;
-            if (s == P.spp) {
+            if (s == s_end) {
                 const size_t pix = (size_t)px + (size_t)py * P.width;
-                P.aov_color[pix] = make_float4(sumL.x * inv_spp, sumL.y * inv_spp, sumL.z * inv_spp, 1.0f);
-                if (P.aov_albedo) P.aov_albedo[pix] = make_float4(sumA.x * inv_spp, sumA.y * inv_spp, sumA.z * inv_spp, 1.0f);
-                if (P.aov_normal) P.aov_normal[pix] = make_float4(sumN.x * inv_spp, sumN.y * inv_spp, sumN.z * inv_spp, 1.0f);
+                if (P.n_chunks == 1u) { // the item is the whole pixel: mean = chunk sum * (1 / spp)
+                    P.aov_color[pix] = make_float4(sumL.x * inv_spp, sumL.y * inv_spp, sumL.z * inv_spp, 1.0f);
+                    if (P.aov_albedo) P.aov_albedo[pix] = make_float4(sumA.x * inv_spp, sumA.y * inv_spp, sumA.z * inv_spp, 1.0f);
+                    if (P.aov_normal) P.aov_normal[pix] = make_float4(sumN.x * inv_spp, sumN.y * inv_spp, sumN.z * inv_spp, 1.0f);
+                } else { // chunk sum -> HBM; hjr_finalize_kernel adds the chunks of a pixel in chunk order
+                    const size_t slot = (size_t)chunk * ((size_t)P.width * P.height) + pix;
+                    P.part_color[slot] = make_float4(sumL.x, sumL.y, sumL.z, 0.0f);
+                    if (P.part_albedo) P.part_albedo[slot] = make_float4(sumA.x, sumA.y, sumA.z, 0.0f);
+                    if (P.part_normal) P.part_normal[slot] = make_float4(sumN.x, sumN.y, sumN.z, 0.0f);
+                }
                 has_pixel = false;
             }
         };
@@ -836,5 +853,29 @@ __global__ void __launch_bounds__(HJR_BLOCK) hjr_render_kernel(const KParams P)
             for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
             if (lane == 0 && v) atomicAdd(&P.stats[i], v);
         }
+    }
+}
+
+// Adds the chunk sums of every owned pixel in chunk order and scales by 1/spp: a fixed summation
+// tree, so the frame is bitwise independent of which lane/wave/GPU rendered which chunk.  Streaming kernel: one lane
+// per pixel, n_chunks coalesced float4 loads, one float4 store.
+__global__ void __launch_bounds__(256) hjr_finalize_kernel(const KParams P)
+{
+    const size_t npix = (size_t)P.width * P.height;
+    const float inv_spp = 1.0f / (float)P.spp;
+    for (size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x; pix < npix; pix += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t x = (uint32_t)(pix % P.width), y = (uint32_t)(pix / P.width);
+        const uint32_t tile = (y / HJR_TILE) * P.tiles_x + (x / HJR_TILE);
+        if (tile % P.world != P.rank) continue;
+        float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f), b = a, c = a;
+        for (uint32_t k = 0; k < P.n_chunks; k++) {
+            const float4 v = P.part_color[(size_t)k * npix + pix];
+            a.x = a.x + v.x; a.y = a.y + v.y; a.z = a.z + v.z;
+            if (P.aov_albedo) { const float4 w = P.part_albedo[(size_t)k * npix + pix]; b.x = b.x + w.x; b.y = b.y + w.y; b.z = b.z + w.z; }
+            if (P.aov_normal) { const float4 w = P.part_normal[(size_t)k * npix + pix]; c.x = c.x + w.x; c.y = c.y + w.y; c.z = c.z + w.z; }
+        }
+        P.aov_color[pix] = make_float4(a.x * inv_spp, a.y * inv_spp, a.z * inv_spp, 1.0f);
+        if (P.aov_albedo) P.aov_albedo[pix] = make_float4(b.x * inv_spp, b.y * inv_spp, b.z * inv_spp, 1.0f);
+        if (P.aov_normal) P.aov_normal[pix] = make_float4(c.x * inv_spp, c.y * inv_spp, c.z * inv_spp, 1.0f);
     }
 }

@@ -28,3 +28,9 @@
 #define HJR_LIGHT_F4 6
 
 #define HJR_NSTAT 10 /* order of hjr_stats' uint64 counters */
+
+/* Work-item chunking: a pixel's spp samples are cut into n_chunks runs of chunk_spp consecutive samples
+ * (a multiple of the 16-sample CMJ pattern, at most 16 runs); pixel mean = ((c0 + c1) + ... ) * (1/spp), ck = in-order sum
+ * of run k.  Depends on spp only, so results do not depend on scheduling, tile sharding or GPU count. */
+static inline uint32_t hjr_chunk_spp(uint32_t spp) { uint32_t n16 = (spp + 15u) / 16u; return 16u * ((n16 + 15u) / 16u); }
+static inline uint32_t hjr_n_chunks(uint32_t spp) { uint32_t s = hjr_chunk_spp(spp); return (spp + s - 1u) / s; }

@@ -1246,10 +1246,21 @@ typedef struct { tctx T; float *color, *albedo, *normal; volatile uint32_t* next
 static void render_pixel(job* J, uint32_t x, uint32_t y)
 {
     const hjo_params* P = J->T.P;
+    /* build-defined accumulation order: samples are summed in order inside runs of chunk_spp
+     * consecutive samples (a multiple of the 16-sample CMJ pattern, at most 16 runs per pixel), and the run sums
+     * are added in run order.  With one run this is the plain in-order sum. */
+    uint32_t n16 = (P->spp + 15u) / 16u;
+    uint32_t chunk = 16u * ((n16 + 15u) / 16u);
     f3 sL = V1(0.0f), sA = V1(0.0f), sN = V1(0.0f);
-    for (uint32_t s = 0; s < P->spp; s++) {
-        f3 L, A, N; sample_one(&J->T, x, y, s, &L, &A, &N);
-        sL = add(sL, L); sA = add(sA, A); sN = add(sN, N);
+    for (uint32_t s0 = 0; s0 < P->spp; s0 += chunk) {
+        uint32_t s1 = s0 + chunk < P->spp ? s0 + chunk : P->spp;
+        f3 cL = V1(0.0f), cA = V1(0.0f), cN = V1(0.0f);
+        for (uint32_t s = s0; s < s1; s++) {
+            f3 L, A, N; sample_one(&J->T, x, y, s, &L, &A, &N);
+            cL = add(cL, L); cA = add(cA, A); cN = add(cN, N);
+        }
+        if (s0 == 0) { sL = cL; sA = cA; sN = cN; }
+        else { sL = add(sL, cL); sA = add(sA, cA); sN = add(sN, cN); }
     }
     float inv = 1.0f / (float)P->spp;
     size_t pix = (size_t)x + (size_t)y * P->width;

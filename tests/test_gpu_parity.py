@@ -41,7 +41,7 @@ def assert_bitexact(a, b, what):
                              % (what, len(bad), a.shape[0] * a.shape[1], x, y, a[y, x], b[y, x]))
 
 
-@pytest.mark.parametrize("w,h,spp", [(64, 64, 4), (40, 24, 3), (256, 256, 16)])
+@pytest.mark.parametrize("w,h,spp", [(64, 64, 4), (40, 24, 3), (256, 256, 16), (48, 32, 40), (24, 16, 272)])
 def test_nee_bitexact_vs_oracle(cornell, dev, oracle, w, h, spp):
     color, albedo, normal = dev.render(cornell.hjr_params(w, h, spp))
     oc, oa, on, st = oracle.render(cornell.oracle_params(w, h, spp))
@@ -94,7 +94,7 @@ def test_frame_and_seed_change_the_stream(cornell, dev, oracle):
 
 def test_tile_sharding_is_exact(cornell, dev):
     """rank r of R renders the 8x8 tiles t with t % R == r; the sum of the shards (zeros elsewhere) is the 1-GPU image."""
-    w, h, spp, R = 200, 120, 3, 3  # ragged: 200 = 25 tiles, 120 = 15 tiles
+    w, h, spp, R = 200, 120, 35, 3  # ragged: 200 = 25 tiles, 120 = 15 tiles; 35 spp = 3 sample chunks per pixel
     full, fa, fn = dev.render(cornell.hjr_params(w, h, spp))
     acc = np.zeros_like(full)
     for r in range(R):

@@ -14,7 +14,7 @@ import numpy as np
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO_ROOT = os.path.dirname(PKG_DIR)
-LIB_PATH = os.path.join(PKG_DIR, "libhenjou_hip.so")
+LIB_PATH = os.environ.get("HJR_LIB") or os.path.join(PKG_DIR, "libhenjou_hip.so")  # HJR_LIB: kernel-variant experiments only
 ASSETS = os.path.join(PKG_DIR, "assets")
 
 INTEGRATOR_NEE, INTEGRATOR_PT, INTEGRATOR_MIS = 0, 1, 2

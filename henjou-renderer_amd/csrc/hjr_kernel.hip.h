@@ -493,7 +493,10 @@ struct Hit { float t, b1, b2; uint32_t k, prim; };
 template <bool ANY, bool STATS, int BLOCK>
 HD bool traverse(const KParams& P, f3 o, f3 d, float tmin, float tmax, Hit& hit, uint32_t* stack, Counters& cnt)
 {
-    const f3 inv = V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    // The slab test only has to be conservative (boxes are padded), so it may use the 1-ulp hardware
+    // reciprocal and fused (lo - o) * inv = fma(lo, inv, -o * inv); the triangle test below is the bit-defined part.
+    const f3 inv = V(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+    const f3 oi = V(-o.x * inv.x, -o.y * inv.y, -o.z * inv.z);
     int sp = 0;
     uint32_t cur = 0;
     hit.prim = 0xffffffffu;
@@ -504,19 +507,19 @@ HD bool traverse(const KParams& P, f3 o, f3 d, float tmin, float tmax, Hit& hit,
             const float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
             const float tfar = hit.t;
             // child 0: lo (q0.x q0.y q0.z) hi (q0.w q1.x q1.y)
-            float t0 = (q0.x - o.x) * inv.x, t1 = (q0.w - o.x) * inv.x;
+            float t0 = fmaf(q0.x, inv.x, oi.x), t1 = fmaf(q0.w, inv.x, oi.x);
             float lo0 = fminf(t0, t1), hi0 = fmaxf(t0, t1);
-            t0 = (q0.y - o.y) * inv.y; t1 = (q1.x - o.y) * inv.y;
+            t0 = fmaf(q0.y, inv.y, oi.y); t1 = fmaf(q1.x, inv.y, oi.y);
             lo0 = fmaxf(lo0, fminf(t0, t1)); hi0 = fminf(hi0, fmaxf(t0, t1));
-            t0 = (q0.z - o.z) * inv.z; t1 = (q1.y - o.z) * inv.z;
+            t0 = fmaf(q0.z, inv.z, oi.z); t1 = fmaf(q1.y, inv.z, oi.z);
             lo0 = fmaxf(lo0, fminf(t0, t1)); hi0 = fminf(hi0, fmaxf(t0, t1));
             lo0 = fmaxf(lo0, tmin); hi0 = fminf(hi0, tfar);
             // child 1: lo (q1.z q1.w q2.x) hi (q2.y q2.z q2.w)
-            t0 = (q1.z - o.x) * inv.x; t1 = (q2.y - o.x) * inv.x;
+            t0 = fmaf(q1.z, inv.x, oi.x); t1 = fmaf(q2.y, inv.x, oi.x);
             float lo1 = fminf(t0, t1), hi1 = fmaxf(t0, t1);
-            t0 = (q1.w - o.y) * inv.y; t1 = (q2.z - o.y) * inv.y;
+            t0 = fmaf(q1.w, inv.y, oi.y); t1 = fmaf(q2.z, inv.y, oi.y);
             lo1 = fmaxf(lo1, fminf(t0, t1)); hi1 = fminf(hi1, fmaxf(t0, t1));
-            t0 = (q2.x - o.z) * inv.z; t1 = (q2.w - o.z) * inv.z;
+            t0 = fmaf(q2.x, inv.z, oi.z); t1 = fmaf(q2.w, inv.z, oi.z);
             lo1 = fmaxf(lo1, fminf(t0, t1)); hi1 = fminf(hi1, fmaxf(t0, t1));
             lo1 = fmaxf(lo1, tmin); hi1 = fminf(hi1, tfar);
             const bool h0 = lo0 <= hi0 * 1.0000004f, h1 = lo1 <= hi1 * 1.0000004f;
@@ -654,8 +657,11 @@ HD void start_path(const KParams& P, PathState& ps, uint32_t px, uint32_t py, ui
     ps.depth = 0;
 }
 
+#ifndef HJR_MIN_WAVES
+#define HJR_MIN_WAVES 1
+#endif
 template <int INTEGRATOR, bool STATS>
-__global__ void __launch_bounds__(HJR_BLOCK) hjr_render_kernel(const KParams P)
+__global__ void __launch_bounds__(HJR_BLOCK, HJR_MIN_WAVES) hjr_render_kernel(const KParams P)
 {
     __shared__ uint32_t s_stack[HJR_STACK_DEPTH * HJR_BLOCK];
     uint32_t* stack = s_stack + threadIdx.x;

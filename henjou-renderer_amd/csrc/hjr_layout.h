@@ -6,7 +6,8 @@
 #define HJR_TILE 8u                 /* 8x8 pixel tiles = one wavefront of pixels */
 #define HJR_STACK_DEPTH 32          /* per-lane traversal stack entries (LDS); the builder caps tree depth at this */
 #define HJR_LEAF_FLAG 0x80000000u   /* child ref: bit31 = leaf, bits 27..30 = triangle count, bits 0..26 = first triangle */
-#define HJR_LEAF_MAX 4u
+#define HJR_LEAF_MAX 4u              /* encoding cap */
+#define HJR_LEAF_DEFAULT 2u          /* builder default: measured fastest on MI355X (profiles/r01_experiments.md) */
 #define HJR_MAX_TRIS (1u << 27)
 
 /* BVH2 node, 64 B = 4 x float4; holds the (padded) boxes of both children.

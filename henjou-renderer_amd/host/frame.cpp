@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -78,6 +79,7 @@ struct Box {
 struct BuildNode { Box box; int left = -1, right = -1; uint32_t first = 0, count = 0; };
 
 struct Builder {
+    uint32_t leaf_max = HJR_LEAF_DEFAULT;
     std::vector<Box> tbox;
     std::vector<float> cent; // 3 per tri
     std::vector<uint32_t> order;
@@ -93,13 +95,13 @@ struct Builder {
         for (uint32_t i = first; i < first + count; i++) { bb.grow(tbox[order[i]]); cb.grow(&cent[3 * order[i]]); }
         nodes[me].box = bb;
         max_depth = std::max(max_depth, depth);
-        if (count <= HJR_LEAF_MAX && (count <= 1 || depth > 0)) { // the root is always split so that it is an inner node
+        if (count <= leaf_max && (count <= 1 || depth > 0)) { // the root is always split so that it is an inner node
             nodes[me].first = first; nodes[me].count = count;
             return me;
         }
         // depth budget: with `levels` levels left a balanced tree must still fit
         uint32_t need = 0;
-        while ((HJR_LEAF_MAX << need) < count) need++;
+        while ((leaf_max << need) < count) need++;
         bool force_median = depth + need + 1 >= HJR_STACK_DEPTH;
         uint32_t mid = first;
         bool have = false;
@@ -223,6 +225,7 @@ bool build_frame(const SceneCopy& sc, const float* M, const float* Mi, uint32_t 
 
     // BVH over padded triangle boxes
     Builder B;
+    if (const char* e = getenv("HJR_LEAF_MAX")) { int v = atoi(e); if (v >= 1 && v <= (int)HJR_LEAF_MAX) B.leaf_max = (uint32_t)v; } // tuning knob
     B.tbox.resize(n); B.cent.resize((size_t)n * 3); B.order.resize(n);
     float smax = 0.0f;
     for (uint32_t t = 0; t < n; t++) {

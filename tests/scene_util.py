@@ -48,3 +48,21 @@ class Cornell:
         d.upload_scene(self.scene.view)
         d.set_transforms(self.arrays["transforms"], self.arrays["inv_transforms"])
         return d
+
+
+def load_lut():
+    return hjr.load_png(os.path.join(hjr.ASSETS, "LUT", "Thin_Film_LUT.png"))
+
+
+class StressScene(Cornell):
+    """tools/make_stress_scene.py output loaded through the product's scene surface."""
+
+    def __init__(self, outdir, spheres=8, segments=32):
+        import subprocess
+        subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_stress_scene.py"), str(outdir),
+                               "--spheres", str(spheres), "--segments", str(segments)], stdout=subprocess.DEVNULL)
+        self.opt = hjr.load_render_option(os.path.join(str(outdir), "render_option_stress.json"))
+        self.scene = hjr.Scene(self.opt.gltf_path.decode(), self.opt.gltf_name.decode(), self.opt)
+        self.time = f32_time(1, self.opt.fps)
+        self.camera = self.scene.camera(self.opt, self.time)
+        self.arrays = self.scene.arrays(self.time)

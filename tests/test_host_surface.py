@@ -166,3 +166,27 @@ def test_gltf_error_paths(tmp_path):
     open(d / "cornelbox.gltf", "w").write(json.dumps(g))
     with pytest.raises(hjr.HjrError):
         hjr.Scene(str(d), "cornelbox.gltf", opt)
+
+
+def test_glb_container(tmp_path):
+    """Binary glTF (gltfloader.h:1086-1091): JSON chunk + BIN chunk; must load to the same SceneData as the .gltf."""
+    import struct
+    src = os.path.join(ASSETS, "Model", "test_gltf")
+    g = json.load(open(os.path.join(src, "cornelbox.gltf")))
+    binary = open(os.path.join(src, "cornelbox.bin"), "rb").read()
+    del g["buffers"][0]["uri"]
+    js = json.dumps(g).encode()
+    js += b" " * ((4 - len(js) % 4) % 4)
+    binary += b"\0" * ((4 - len(binary) % 4) % 4)
+    total = 12 + 8 + len(js) + 8 + len(binary)
+    blob = struct.pack("<4sII", b"glTF", 2, total) + struct.pack("<II", len(js), 0x4E4F534A) + js + \
+        struct.pack("<II", len(binary), 0x004E4942) + binary
+    (tmp_path / "c.glb").write_bytes(blob)
+    opt = hjr.load_render_option(os.path.join(ASSETS, "render_option_c1.json"))
+    a = hjr.Scene(str(tmp_path), "c.glb", opt).arrays()
+    b = Cornell().arrays
+    for k in ("vertices", "normals", "texcoords", "material_ids", "prim_offsets", "light_prim_ids"):
+        assert np.array_equal(a[k], b[k]), k
+    (tmp_path / "bad.glb").write_bytes(blob[:40])
+    with pytest.raises(hjr.HjrError):
+        hjr.Scene(str(tmp_path), "bad.glb", opt)

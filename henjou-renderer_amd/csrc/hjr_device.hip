@@ -160,17 +160,34 @@ extern "C" int hjr_set_lut(hjr_ctx* c, const uint8_t* rgba, int w, int h)
     return HJR_OK;
 }
 
+#define HJR_BLOCK_LDS 768 /* 12 wavefronts = 3 per SIMD: one workgroup per CU shares the LDS copy of the BVH */
+#define HJR_LDS_BUDGET (160u * 1024u)
+
 // persistent grid = resident workgroups only: CUs x (workgroups the kernel's VGPR/LDS budget admits per CU), capped by the
 // number of wavefront-sized batches of work; HJR_BLOCKS_PER_CU overrides the occupancy query
-template <int I, bool S> static void launch(const hjr_ctx* c, const KParams& kp, uint64_t max_useful, hipStream_t st)
+template <int I, bool S> static int launch(const hjr_ctx* c, const KParams& kp, uint64_t n_items, bool lds_bvh, hipStream_t st)
 {
+    if (lds_bvh) {
+        const size_t smem = (size_t)HJR_BLOCK_LDS * kp.stack_depth * 4 + ((size_t)kp.n_node_f4 + kp.n_tri_f4) * 16;
+        auto kern = hjr_render_kernel<I, S, HJR_BLOCK_LDS, true>;
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return -1;
+        uint64_t blocks = (uint64_t)c->n_cus;
+        uint64_t max_useful = (n_items + HJR_BLOCK_LDS - 1) / HJR_BLOCK_LDS;
+        if (blocks > max_useful) blocks = max_useful ? max_useful : 1;
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(HJR_BLOCK_LDS), smem, st, kp);
+        return 0;
+    }
+    const size_t smem = (size_t)HJR_BLOCK * kp.stack_depth * 4;
+    auto kern = hjr_render_kernel<I, S, HJR_BLOCK, false>;
     int per_cu = 0;
     if (c->blocks_per_cu > 0) per_cu = c->blocks_per_cu;
-    else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)hjr_render_kernel<I, S>, HJR_BLOCK, 0) != hipSuccess || per_cu < 1)
+    else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, HJR_BLOCK, smem) != hipSuccess || per_cu < 1)
         per_cu = 2;
     uint64_t blocks = (uint64_t)c->n_cus * (uint64_t)per_cu;
-    if (blocks > max_useful) blocks = max_useful;
-    hipLaunchKernelGGL((hjr_render_kernel<I, S>), dim3((unsigned)blocks), dim3(HJR_BLOCK), 0, st, kp);
+    uint64_t max_useful = (n_items + HJR_BLOCK - 1) / HJR_BLOCK;
+    if (blocks > max_useful) blocks = max_useful ? max_useful : 1;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(HJR_BLOCK), smem, st, kp);
+    return 0;
 }
 
 static int render_impl(hjr_ctx* c, const hjr_params* p, void* d_color, void* d_albedo, void* d_normal, hipStream_t st)
@@ -191,7 +208,7 @@ static int render_impl(hjr_ctx* c, const hjr_params* p, void* d_color, void* d_a
     if (n_items >= 0xffffffffull) { set_error("hjr_render: image too large"); return HJR_ERR_ARG; }
 
     // work area: [0] queue head, [16..] HJR_NSTAT uint64 counters
-    const size_t work_bytes = 16 + HJR_NSTAT * 8;
+    const size_t work_bytes = 16 + (HJR_NSTAT + 6) * 8; // +6: phase clocks of the HJR_TIMING diagnostic build
     if (c->d_work.cap < work_bytes) {
         std::vector<unsigned char> z(work_bytes, 0);
         if (!c->d_work.upload(z.data(), work_bytes, st)) { set_error("hjr_render: work buffer allocation failed"); return HJR_ERR_DEVICE; }
@@ -245,19 +262,26 @@ static int render_impl(hjr_ctx* c, const hjr_params* p, void* d_color, void* d_a
     }
     kp.cam_f = p->camera.f;
 
-    uint64_t max_useful = (n_items + HJR_BLOCK - 1) / HJR_BLOCK;
-    if (max_useful < 1) max_useful = 1;
     const bool stats = (p->flags & HJR_FLAG_STATS) != 0;
+    kp.n_node_f4 = c->frame.n_nodes * HJR_NODE_F4;
+    kp.n_tri_f4 = (c->frame.n_tris ? c->frame.n_tris : 1u) * HJR_TRI_F4;
+    kp.stack_depth = c->frame.depth + 2; // pushes <= depth of the deepest inner node; +1 slack, rounded so that BLOCK * depth % 4 == 0
+    // stage the whole BVH in LDS when it fits beside the traversal stacks of one 768-thread workgroup (HJR_LDS_BVH=0 disables)
+    const size_t lds_need = (size_t)HJR_BLOCK_LDS * kp.stack_depth * 4 + ((size_t)kp.n_node_f4 + kp.n_tri_f4) * 16;
+    bool lds_bvh = lds_need <= HJR_LDS_BUDGET - 1024;
+    if (const char* e = getenv("HJR_LDS_BVH")) lds_bvh = lds_bvh && atoi(e) != 0;
 
     HIPCHK(hipEventRecord(c->ev0, st));
+    int lrc = 0;
     switch (p->integrator * 2 + (stats ? 1 : 0)) {
-    case 0: launch<HJR_INTEGRATOR_NEE, false>(c, kp, max_useful, st); break;
-    case 1: launch<HJR_INTEGRATOR_NEE, true>(c, kp, max_useful, st); break;
-    case 2: launch<HJR_INTEGRATOR_PT, false>(c, kp, max_useful, st); break;
-    case 3: launch<HJR_INTEGRATOR_PT, true>(c, kp, max_useful, st); break;
-    case 4: launch<HJR_INTEGRATOR_MIS, false>(c, kp, max_useful, st); break;
-    default: launch<HJR_INTEGRATOR_MIS, true>(c, kp, max_useful, st); break;
+    case 0: lrc = launch<HJR_INTEGRATOR_NEE, false>(c, kp, n_items, lds_bvh, st); break;
+    case 1: lrc = launch<HJR_INTEGRATOR_NEE, true>(c, kp, n_items, lds_bvh, st); break;
+    case 2: lrc = launch<HJR_INTEGRATOR_PT, false>(c, kp, n_items, lds_bvh, st); break;
+    case 3: lrc = launch<HJR_INTEGRATOR_PT, true>(c, kp, n_items, lds_bvh, st); break;
+    case 4: lrc = launch<HJR_INTEGRATOR_MIS, false>(c, kp, n_items, lds_bvh, st); break;
+    default: lrc = launch<HJR_INTEGRATOR_MIS, true>(c, kp, n_items, lds_bvh, st); break;
     }
+    if (lrc != 0) { set_error("hjr_render: could not reserve dynamic LDS for the BVH"); return HJR_ERR_DEVICE; }
     HIPCHK(hipGetLastError());
     if (n_chunks > 1) {
         const size_t npix = (size_t)p->width * p->height;
@@ -277,6 +301,15 @@ static int fetch_stats(hjr_ctx* c, hipStream_t st)
     HIPCHK(hipStreamSynchronize(st));
     uint64_t* dst = &c->stats.samples;
     for (int i = 0; i < HJR_NSTAT; i++) dst[i] = h[i];
+#ifdef HJR_TIMING
+    {
+        unsigned long long tk[6];
+        HIPCHK(hipMemcpy(tk, (char*)c->d_work.p + 16 + HJR_NSTAT * 8, sizeof(tk), hipMemcpyDeviceToHost));
+        double tot = 0; for (int i = 0; i < 6; i++) tot += (double)tk[i];
+        fprintf(stderr, "[hjr timing] rr/regen %.1f%%  trace %.1f%%  resolve+hit %.1f%%  nee(light+eval) %.1f%%  bsdf sample %.1f%%  rest %.1f%%  (total %.3g wave-clocks)\n",
+                100 * tk[0] / tot, 100 * tk[1] / tot, 100 * tk[2] / tot, 100 * tk[3] / tot, 100 * tk[4] / tot, 100 * tk[5] / tot, tot);
+    }
+#endif
     return HJR_OK;
 }
 

@@ -36,6 +36,8 @@ struct KParams {
     uint32_t tiles_x, n_owned_items; // items = owned tiles * n_chunks * 64
     uint32_t rank, world;
     uint32_t chunk_spp, n_chunks;    // samples per work item, work items per pixel (hjr_chunking)
+    uint32_t n_node_f4, n_tri_f4;    // float4 counts of nodes[] / tri_geom[] (LDS staging)
+    uint32_t stack_depth;            // traversal stack entries per lane (BVH depth + 1)
     float4* part_color;              // [n_chunks][height][width] chunk sums when n_chunks > 1
     float4* part_albedo;
     float4* part_normal;
@@ -491,7 +493,7 @@ struct Hit { float t, b1, b2; uint32_t k, prim; };
 
 // stack: this lane's column of the LDS stack, element i at stack[i * BLOCK]
 template <bool ANY, bool STATS, int BLOCK>
-HD bool traverse(const KParams& P, f3 o, f3 d, float tmin, float tmax, Hit& hit, uint32_t* stack, Counters& cnt)
+HD bool traverse(const float4* nodes, const float4* tris, f3 o, f3 d, float tmin, float tmax, Hit& hit, uint32_t* stack, Counters& cnt)
 {
     // The slab test only has to be conservative (boxes are padded), so it may use the 1-ulp hardware
     // reciprocal and fused (lo - o) * inv = fma(lo, inv, -o * inv); the triangle test below is the bit-defined part.
@@ -503,7 +505,7 @@ HD bool traverse(const KParams& P, f3 o, f3 d, float tmin, float tmax, Hit& hit,
     hit.t = tmax;
     for (;;) {
         if (!(cur & HJR_LEAF_FLAG)) {
-            const float4* nd = P.nodes + (size_t)cur * HJR_NODE_F4;
+            const float4* nd = nodes + cur * HJR_NODE_F4;
             const float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
             const float tfar = hit.t;
             // child 0: lo (q0.x q0.y q0.z) hi (q0.w q1.x q1.y)
@@ -537,7 +539,7 @@ HD bool traverse(const KParams& P, f3 o, f3 d, float tmin, float tmax, Hit& hit,
         } else {
             const uint32_t first = cur & 0x07ffffffu, count = (cur >> 27) & 15u;
             for (uint32_t i = 0; i < count; i++) {
-                const float4* g = P.tri_geom + (size_t)(first + i) * HJR_TRI_F4;
+                const float4* g = tris + (first + i) * HJR_TRI_F4;
                 const float4 g0 = g[0], g1 = g[1], g2 = g[2];
                 float t, b1, b2;
                 if (STATS) cnt.tri++;
@@ -558,6 +560,97 @@ HD bool traverse(const KParams& P, f3 o, f3 d, float tmin, float tmax, Hit& hit,
     return hit.prim != 0xffffffffu;
 }
 
+// Fused traversal of two rays per lane in ONE loop: ray A = the pending NEE shadow ray of the bounce just shaded (any-hit),
+// ray B = the next closest-hit ray (continuation or a regenerated primary ray).  A lane moves on to B the moment its A is
+// resolved, without waiting for the rest of the wave, so the wave's trip count is max_lanes(tripsA + tripsB) instead of
+// max(tripsA) + max(tripsB) — the SIMT cost of per-lane trip-count variance drops by ~1/3 (profiles/r01_experiments.md).
+// Results are identical to two separate traversals.
+#define HJR_TRAV_DONE 0xffffffffu
+template <bool STATS, int BLOCK>
+HD void traverse_fused(const float4* nodes, const float4* tris, const bool a_valid, const f3 ao, const f3 ad, const float a_tmax, const bool b_valid,
+                       const f3 bo, const f3 bd, bool& occluded, Hit& hit, uint32_t* stack, Counters& ca, Counters& cb)
+{
+    const float tmin = 0.001f;
+    occluded = false;
+    hit.prim = 0xffffffffu;
+    hit.t = 1e16f;
+    int phase = a_valid ? 0 : (b_valid ? 1 : 2);
+    f3 o = (phase == 0) ? ao : bo;
+    f3 d = (phase == 0) ? ad : bd;
+    // conservative slab test: hardware reciprocal + fma (boxes are padded)
+    f3 inv = V(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+    f3 oi = V(-o.x * inv.x, -o.y * inv.y, -o.z * inv.z);
+    int sp = 0;
+    uint32_t cur = (phase < 2) ? 0u : HJR_TRAV_DONE;
+    while (phase < 2) {
+        // "while-while" traversal: every lane first descends through inner nodes until it holds a leaf (or is out of work) ...
+        while (!(cur & HJR_LEAF_FLAG)) {
+            const float4* nd = nodes + cur * HJR_NODE_F4;
+            const float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
+            const float tfar = (phase == 0) ? a_tmax : hit.t;
+            float t0 = fmaf(q0.x, inv.x, oi.x), t1 = fmaf(q0.w, inv.x, oi.x);
+            float lo0 = fminf(t0, t1), hi0 = fmaxf(t0, t1);
+            t0 = fmaf(q0.y, inv.y, oi.y); t1 = fmaf(q1.x, inv.y, oi.y);
+            lo0 = fmaxf(lo0, fminf(t0, t1)); hi0 = fminf(hi0, fmaxf(t0, t1));
+            t0 = fmaf(q0.z, inv.z, oi.z); t1 = fmaf(q1.y, inv.z, oi.z);
+            lo0 = fmaxf(lo0, fminf(t0, t1)); hi0 = fminf(hi0, fmaxf(t0, t1));
+            lo0 = fmaxf(lo0, tmin); hi0 = fminf(hi0, tfar);
+            t0 = fmaf(q1.z, inv.x, oi.x); t1 = fmaf(q2.y, inv.x, oi.x);
+            float lo1 = fminf(t0, t1), hi1 = fmaxf(t0, t1);
+            t0 = fmaf(q1.w, inv.y, oi.y); t1 = fmaf(q2.z, inv.y, oi.y);
+            lo1 = fmaxf(lo1, fminf(t0, t1)); hi1 = fminf(hi1, fmaxf(t0, t1));
+            t0 = fmaf(q2.x, inv.z, oi.z); t1 = fmaf(q2.w, inv.z, oi.z);
+            lo1 = fmaxf(lo1, fminf(t0, t1)); hi1 = fminf(hi1, fmaxf(t0, t1));
+            lo1 = fmaxf(lo1, tmin); hi1 = fminf(hi1, tfar);
+            const bool h0 = lo0 <= hi0 * 1.0000004f, h1 = lo1 <= hi1 * 1.0000004f;
+            const uint32_t c0 = f2bits(q3.x), c1 = f2bits(q3.y);
+            if (STATS) { if (phase == 0) ca.box += 2; else cb.box += 2; }
+            if (h0 && h1) {
+                const bool swap = lo1 < lo0;
+                stack[sp * BLOCK] = swap ? c0 : c1;
+                sp++;
+                cur = swap ? c1 : c0;
+            } else if (h0) cur = c0;
+            else if (h1) cur = c1;
+            else if (sp > 0) { sp--; cur = stack[sp * BLOCK]; }
+            else cur = HJR_TRAV_DONE;
+        }
+        // ... then all lanes test their leaf's triangles together
+        bool done = (cur == HJR_TRAV_DONE);
+        if (!done) {
+            const uint32_t first = cur & 0x07ffffffu, count = (cur >> 27) & 15u;
+            const float tri_tmax = (phase == 0) ? a_tmax : 1e16f;
+            for (uint32_t i = 0; i < count; i++) {
+                const float4* g = tris + (first + i) * HJR_TRI_F4;
+                const float4 g0 = g[0], g1 = g[1], g2 = g[2];
+                float t, b1, b2;
+                if (STATS) { if (phase == 0) ca.tri++; else cb.tri++; }
+                if (ray_tri(V(g0.x, g0.y, g0.z), V(g0.w, g1.x, g1.y), V(g1.z, g1.w, g2.x), o, d, tmin, tri_tmax, t, b1, b2)) {
+                    if (phase == 0) { occluded = true; done = true; break; }
+                    const uint32_t prim = f2bits(g2.y);
+                    // order-independent closest-hit rule: smaller t wins; equal t -> smaller global prim id
+                    if (hit.prim == 0xffffffffu || t < hit.t || (t == hit.t && prim < hit.prim)) {
+                        hit.t = t; hit.b1 = b1; hit.b2 = b2; hit.k = first + i; hit.prim = prim;
+                    }
+                }
+            }
+            if (!done) {
+                if (sp > 0) { sp--; cur = stack[sp * BLOCK]; }
+                else done = true;
+            }
+        }
+        if (done) {
+            if (phase == 0 && b_valid) { // this lane's shadow ray is resolved: start its closest-hit ray right away
+                phase = 1;
+                o = bo; d = bd;
+                inv = V(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+                oi = V(-o.x * inv.x, -o.y * inv.y, -o.z * inv.z);
+                sp = 0; cur = 0;
+            } else { phase = 2; cur = HJR_TRAV_DONE; }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ closest-hit / miss programs (build-defined)
 struct HitInfo { // the Payload fields the integrators read (kernel/Payload.h:12-42)
     bool is_hit, is_light;
@@ -566,24 +659,23 @@ struct HitInfo { // the Payload fields the integrators read (kernel/Payload.h:12
     uint32_t prim;
 };
 
-template <bool STATS, int BLOCK>
-HD void ray_trace(const KParams& P, f3 o, f3 d, HitInfo& prd, uint32_t* stack, unsigned long long* lc)
+// __closesthit__ch / __miss__ms for a finished closest-hit traversal
+template <bool STATS>
+HD void hit_program(const KParams& P, const float4* tris, const Hit& h, HitInfo& prd, unsigned long long* lc)
 {
-    Hit h;
-    Counters c; c.box = 0; c.tri = 0;
-    const bool got = traverse<false, STATS, BLOCK>(P, o, d, 0.001f, 1e16f, h, stack, c);
-    if (STATS) { lc[1] += 1; lc[3] += c.box; lc[4] += c.tri; }
-    if (!got) { // __miss__ms: constant sky (use_IBL = false: 1x1 texel scene_sky_default, renderer.h:802-851) * ibl_intensity
+    if (h.prim == 0xffffffffu) { // __miss__ms: constant sky (use_IBL = false: 1x1 texel scene_sky_default, renderer.h:802-851) * ibl_intensity
         prd.is_hit = false; prd.is_light = false;
         prd.emission = V(P.sky[0], P.sky[1], P.sky[2]);
         prd.position = V1(0.0f); prd.normal = V1(0.0f);
         prd.surf.basecolor = V1(0.0f); // Payload default (Payload.h:25)
+        prd.surf.metallic = 0.0f; prd.surf.roughness = 0.0f; prd.surf.sheen = 0.0f; prd.surf.clearcoat = 0.0f; prd.surf.ior = 1.0f;
+        prd.surf.is_specular = false; prd.surf.is_thinfilm = false;
         prd.prim = 0xffffffffu;
         return;
     }
     // __closesthit__ch: barycentric interpolation of the pre-transformed vertices / normals with (1-b1-b2, b1, b2);
     // the interpolated normal is neither re-normalised nor flipped (stale ptx:1244-1283)
-    const float4* g = P.tri_geom + (size_t)h.k * HJR_TRI_F4;
+    const float4* g = tris + h.k * HJR_TRI_F4;
     const float4 g0 = g[0], g1 = g[1], g2 = g[2];
     const float4* s = P.tri_shade + (size_t)h.prim * HJR_SHADE_F4;
     const float4 s0 = s[0], s1 = s[1], s2 = s[2], s3 = s[3];
@@ -602,6 +694,17 @@ HD void ray_trace(const KParams& P, f3 o, f3 d, HitInfo& prd, uint32_t* stack, u
     prd.surf.is_thinfilm = f2bits(m3.z) != 0;
     prd.prim = h.prim;
     if (STATS) lc[7] += 1;
+}
+
+// RayTrace (rt.h:43-69): stand-alone closest-hit query (used by MIS' BSDF-sampled light ray)
+template <bool STATS, int BLOCK>
+HD void ray_trace(const KParams& P, const float4* nodes, const float4* tris, f3 o, f3 d, HitInfo& prd, uint32_t* stack, unsigned long long* lc)
+{
+    Hit h;
+    Counters c; c.box = 0; c.tri = 0;
+    traverse<false, STATS, BLOCK>(nodes, tris, o, d, 0.001f, 1e16f, h, stack, c);
+    if (STATS) { lc[1] += 1; lc[3] += c.box; lc[4] += c.tri; }
+    hit_program<STATS>(P, tris, h, prd, lc);
 }
 
 // light_sample (kernel/light_sample.h:9-75) on the per-frame light table
@@ -660,29 +763,58 @@ HD void start_path(const KParams& P, PathState& ps, uint32_t px, uint32_t py, ui
 #ifndef HJR_MIN_WAVES
 #define HJR_MIN_WAVES 1
 #endif
-template <int INTEGRATOR, bool STATS>
-__global__ void __launch_bounds__(HJR_BLOCK, HJR_MIN_WAVES) hjr_render_kernel(const KParams P)
+// Dynamic LDS: [traversal stacks: stack_depth x BLOCK uint32][nodes][tri_geom]  (the last two only when LDSBVH).
+// LDSBVH: the whole BVH + leaf-order triangles are staged into LDS once per persistent workgroup (coalesced dwordx4 loads),
+// so every traversal step reads LDS (ds_read_b128, ~100-cycle latency) instead of L2 (~500+ cycles under load).  One
+// workgroup of BLOCK threads per CU shares the copy.  Chosen by the host when the scene fits (hjr_device.hip).
+extern __shared__ float4 hjr_smem[];
+
+template <int INTEGRATOR, bool STATS, int BLOCK, bool LDSBVH>
+__global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_render_kernel(const KParams P)
 {
-    __shared__ uint32_t s_stack[HJR_STACK_DEPTH * HJR_BLOCK];
-    uint32_t* stack = s_stack + threadIdx.x;
+    uint32_t* stack = reinterpret_cast<uint32_t*>(hjr_smem) + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
+    const float4* nodes = P.nodes;
+    const float4* tris = P.tri_geom;
+    if (LDSBVH) {
+        float4* l_nodes = hjr_smem + (BLOCK * P.stack_depth) / 4u;
+        float4* l_tris = l_nodes + P.n_node_f4;
+        for (uint32_t i = threadIdx.x; i < P.n_node_f4; i += BLOCK) l_nodes[i] = P.nodes[i];
+        for (uint32_t i = threadIdx.x; i < P.n_tri_f4; i += BLOCK) l_tris[i] = P.tri_geom[i];
+        __syncthreads();
+        nodes = l_nodes;
+        tris = l_tris;
+    }
 
     unsigned long long lc[HJR_NSTAT];
     if (STATS) for (int i = 0; i < HJR_NSTAT; i++) lc[i] = 0;
 
-    bool has_pixel = false, dead = false, path_live = false;
+    bool has_item = false, dead = false, path_live = false;
+    bool fin_pending = false;   // a finished path whose L still waits for its last NEE shadow ray
+    bool write_pending = false; // the item's last sample is finished; sums go out once fin_pending is resolved
+    bool sh_valid = false;      // pending NEE shadow ray of the bounce shaded in the previous iteration
     uint32_t px = 0, py = 0, s = 0, s_end = 0, chunk = 0;
     f3 sumL = V1(0.0f), sumA = V1(0.0f), sumN = V1(0.0f);
+    f3 sh_o = V1(0.0f), sh_d = V1(0.0f), sh_contrib = V1(0.0f), fin_L = V1(0.0f);
+    float sh_tmax = 0.0f;
     PathState ps;
     ps.ro = ps.rd = ps.thr = ps.L = V1(0.0f);
     ps.depth = 0;
     ps.st.n_spp = 0; ps.st.scramble = 0; ps.st.depth = 0; ps.st.image_idx = 0;
     const float inv_spp = 1.0f / (float)P.spp;
+#ifdef HJR_TIMING
+    // diagnostic build: wave-clock shares of the loop's phases, summed per wave into P.stats[10..15] (never in the shipped build)
+    unsigned long long tk[6] = { 0, 0, 0, 0, 0, 0 };
+    unsigned long long tstamp = __builtin_amdgcn_s_memtime();
+#define HJR_TICK(i) { unsigned long long now_ = __builtin_amdgcn_s_memtime(); tk[i] += now_ - tstamp; tstamp = now_; }
+#else
+#define HJR_TICK(i)
+#endif
 
     for (;;) {
-        // ---- ray-queue refill: one wave-aggregated atomic hands out pixels to every idle lane (ballot + mbcnt prefix)
+        // ---- ray-queue refill: one wave-aggregated atomic hands out work items to every idle lane (ballot + mbcnt prefix)
         {
-            const bool need = !has_pixel && !dead;
+            const bool need = !has_item && !dead && !write_pending && !fin_pending && !sh_valid;
             const unsigned long long m = __ballot(need);
             if (m) {
                 const uint32_t n = (uint32_t)__popcll(m);
@@ -703,7 +835,7 @@ __global__ void __launch_bounds__(HJR_BLOCK, HJR_MIN_WAVES) hjr_render_kernel(co
                         px = tx * HJR_TILE + (q & 7u);
                         py = ty * HJR_TILE + ((q >> 3) & 7u);
                         if (px < P.width && py < P.height) {
-                            has_pixel = true; path_live = false;
+                            has_item = true; path_live = false;
                             s = chunk * P.chunk_spp;
                             s_end = min(s + P.chunk_spp, P.spp);
                             sumL = V1(0.0f); sumA = V1(0.0f); sumN = V1(0.0f);
@@ -711,54 +843,88 @@ __global__ void __launch_bounds__(HJR_BLOCK, HJR_MIN_WAVES) hjr_render_kernel(co
                     } else dead = true;
                 }
             }
-            if (__ballot(!dead) == 0ull) break;
+            if (__ballot(!dead) == 0ull) break; // a lane only dies with nothing pending
         }
 
-        // end of a path: NaN/Inf guard, ordered accumulation, next sample or pixel write-out
-        auto end_path = [&]() {
-            float sum = ps.L.x + ps.L.y + ps.L.z;
-            if (!(sum - sum == 0.0f)) { ps.L = V1(0.0f); if (STATS) lc[9] += 1; }
-            sumL = sumL + ps.L;
+        // NaN/Inf guard + ordered accumulation of one finished sample
+        auto finish_sample = [&](f3 L) {
+            float sum = L.x + L.y + L.z;
+            if (!(sum - sum == 0.0f)) { L = V1(0.0f); if (STATS) lc[9] += 1; }
+            sumL = sumL + L;
             if (STATS) lc[0] += 1;
+        };
+        // sample bookkeeping at the end of a path (independent of the radiance value)
+        auto close_sample = [&]() {
             s++;
             path_live = false;
-            if (s == s_end) {
-                const size_t pix = (size_t)px + (size_t)py * P.width;
-                if (P.n_chunks == 1u) { // the item is the whole pixel: mean = chunk sum * (1 / spp)
-                    P.aov_color[pix] = make_float4(sumL.x * inv_spp, sumL.y * inv_spp, sumL.z * inv_spp, 1.0f);
-                    if (P.aov_albedo) P.aov_albedo[pix] = make_float4(sumA.x * inv_spp, sumA.y * inv_spp, sumA.z * inv_spp, 1.0f);
-                    if (P.aov_normal) P.aov_normal[pix] = make_float4(sumN.x * inv_spp, sumN.y * inv_spp, sumN.z * inv_spp, 1.0f);
-                } else { // chunk sum -> HBM; hjr_finalize_kernel adds the chunks of a pixel in chunk order
-                    const size_t slot = (size_t)chunk * ((size_t)P.width * P.height) + pix;
-                    P.part_color[slot] = make_float4(sumL.x, sumL.y, sumL.z, 0.0f);
-                    if (P.part_albedo) P.part_albedo[slot] = make_float4(sumA.x, sumA.y, sumA.z, 0.0f);
-                    if (P.part_normal) P.part_normal[slot] = make_float4(sumN.x, sumN.y, sumN.z, 0.0f);
-                }
-                has_pixel = false;
+            if (s == s_end) { write_pending = true; has_item = false; }
+        };
+        auto write_out = [&]() {
+            const size_t pix = (size_t)px + (size_t)py * P.width;
+            if (P.n_chunks == 1u) { // the item is the whole pixel: mean = chunk sum * (1 / spp)
+                P.aov_color[pix] = make_float4(sumL.x * inv_spp, sumL.y * inv_spp, sumL.z * inv_spp, 1.0f);
+                if (P.aov_albedo) P.aov_albedo[pix] = make_float4(sumA.x * inv_spp, sumA.y * inv_spp, sumA.z * inv_spp, 1.0f);
+                if (P.aov_normal) P.aov_normal[pix] = make_float4(sumN.x * inv_spp, sumN.y * inv_spp, sumN.z * inv_spp, 1.0f);
+            } else { // chunk sum -> HBM; hjr_finalize_kernel adds the chunks of a pixel in chunk order
+                const size_t slot = (size_t)chunk * ((size_t)P.width * P.height) + pix;
+                P.part_color[slot] = make_float4(sumL.x, sumL.y, sumL.z, 0.0f);
+                if (P.part_albedo) P.part_albedo[slot] = make_float4(sumA.x, sumA.y, sumA.z, 0.0f);
+                if (P.part_normal) P.part_normal[slot] = make_float4(sumN.x, sumN.y, sumN.z, 0.0f);
             }
+            write_pending = false;
         };
 
         // ---- Russian roulette (rt.h:173-179) with in-place path regeneration: a lane whose path dies here starts its
-        //      next sample immediately, so it still has a ray for this iteration's trace
+        //      next sample immediately, so it still has a closest-hit ray for this iteration's trace.  The dead path's
+        //      radiance is final only after its pending shadow ray (fused into the same trace) is resolved.
         bool tracing = false;
-        while (has_pixel) {
+        while (has_item) {
             if (!path_live) { start_path(P, ps, px, py, s); path_live = true; }
             const float russian_p = fmaxf(ps.thr.x, fmaxf(ps.thr.y, ps.thr.z));
-            if (russian_p < cmj_1d(ps.st)) { end_path(); continue; }
+            if (russian_p < cmj_1d(ps.st)) { fin_pending = true; fin_L = ps.L; close_sample(); continue; }
             ps.thr = ps.thr / russian_p;
             tracing = true;
             break;
         }
 
+        HJR_TICK(0)
+        // ---- one fused traversal: pending shadow ray (TraceOcculution, rt.h:236-243) then closest-hit ray (RayTrace, rt.h:182-189)
+        bool occluded = false;
+        Hit h;
+        {
+            Counters ca, cb; ca.box = ca.tri = cb.box = cb.tri = 0;
+            traverse_fused<STATS, BLOCK>(nodes, tris, sh_valid, sh_o, sh_d, sh_tmax, tracing, ps.ro, ps.rd, occluded, h, stack, ca, cb);
+            if (STATS) {
+                if (sh_valid) { lc[2] += 1; lc[5] += ca.box; lc[6] += ca.tri; }
+                if (tracing) { lc[1] += 1; lc[3] += cb.box; lc[4] += cb.tri; }
+            }
+        }
+        HJR_TICK(1)
+        if (sh_valid) { // `if (!light_shot.is_hit) LTE += ...` (rt.h:245-259), added to the path the shadow ray belongs to
+            if (!occluded) {
+                if (fin_pending) fin_L = fin_L + sh_contrib;
+                else ps.L = ps.L + sh_contrib;
+            }
+            sh_valid = false;
+        }
+        if (fin_pending) {
+            finish_sample(fin_L);
+            fin_pending = false;
+            if (write_pending) write_out();
+        }
+
         if (tracing) {
             HitInfo prd;
-            ray_trace<STATS, HJR_BLOCK>(P, ps.ro, ps.rd, prd, stack, lc);
+            hit_program<STATS>(P, tris, h, prd, lc);
             if (ps.depth == 0) { sumA = sumA + prd.surf.basecolor; sumN = sumN + prd.normal; } // rt.h:191-194
             if (!prd.is_hit || prd.is_light) {
                 // NEE / MIS count emission only at depth 0 (rt.h:196-208, 318-330); Pathtrace always (rt.h:118-126)
                 if (INTEGRATOR == HJR_INTEGRATOR_PT_ || ps.depth == 0) ps.L = ps.L + ps.thr * prd.emission;
-                end_path();
+                finish_sample(ps.L);
+                close_sample();
+                if (write_pending) write_out();
             } else {
+                HJR_TICK(2)
                 const Surface& sf = prd.surf;
                 f3 t, b;
                 const f3 n = prd.normal;
@@ -781,34 +947,42 @@ __global__ void __launch_bounds__(HJR_BLOCK, HJR_MIN_WAVES) hjr_render_kernel(co
                         light_distance = length3(sd);
                         sd = normalize(sd);
                     }
-                    Hit sh;
-                    Counters c; c.box = 0; c.tri = 0;
-                    const bool occluded = traverse<true, STATS, HJR_BLOCK>(P, so, sd, 0.001f, light_distance - 0.001f, sh, stack, c);
-                    if (STATS) { lc[2] += 1; lc[5] += c.box; lc[6] += c.tri; }
-                    if (!occluded) {
-                        const float cosine1 = absdot(n, sd);
-                        const float cosine2 = absdot(light_normal, -sd);
-                        const f3 local_wi = world_to_local(sd, t, n, b);
-                        const f3 bsdf = bsdf_eval(P, sf, local_wo, local_wi);
-                        const float G = cosine2 / (light_distance * light_distance);
-                        if (INTEGRATOR == HJR_INTEGRATOR_NEE_) {
-                            ps.L = ps.L + (ps.thr * ((bsdf * G * cosine1) / light_pdf)) * light_color; // rt.h:258
-                        } else {
-                            const float pt_pdf = bsdf_pdf(sf, local_wo, local_wi) * G;
-                            const float mis_weight = light_pdf / (light_pdf + pt_pdf);
-                            ps.L = ps.L + ((ps.thr * ((bsdf * G * cosine1) / light_pdf)) * mis_weight) * light_color; // rt.h:378
-                        }
+                    // the contribution is fully determined here; only whether it is added depends on the shadow ray, which is
+                    // traced fused with the next closest-hit ray at the top of the next iteration
+                    const float cosine1 = absdot(n, sd);
+                    const float cosine2 = absdot(light_normal, -sd);
+                    const f3 local_wi = world_to_local(sd, t, n, b);
+                    const f3 bsdf = bsdf_eval(P, sf, local_wo, local_wi);
+                    const float G = cosine2 / (light_distance * light_distance);
+                    if (INTEGRATOR == HJR_INTEGRATOR_NEE_) {
+                        sh_contrib = (ps.thr * ((bsdf * G * cosine1) / light_pdf)) * light_color; // rt.h:258
+                    } else {
+                        const float pt_pdf = bsdf_pdf(sf, local_wo, local_wi) * G;
+                        const float mis_weight = light_pdf / (light_pdf + pt_pdf);
+                        sh_contrib = ((ps.thr * ((bsdf * G * cosine1) / light_pdf)) * mis_weight) * light_color; // rt.h:378
                     }
+                    sh_o = so; sh_d = sd; sh_tmax = light_distance - 0.001f;
+                    sh_valid = true;
                 }
 
                 if (INTEGRATOR == HJR_INTEGRATOR_MIS_) { // BSDF-sampled light hit, rt.h:383-420
+                    // MIS adds this term AFTER the NEE term of the same bounce (rt.h:378 then :414/:418); the NEE term is still
+                    // pending, so resolve its shadow ray now to keep the order of the float additions
+                    if (sh_valid) {
+                        Hit shh;
+                        Counters c; c.box = 0; c.tri = 0;
+                        const bool occ = traverse<true, STATS, BLOCK>(nodes, tris, sh_o, sh_d, 0.001f, sh_tmax, shh, stack, c);
+                        if (STATS) { lc[2] += 1; lc[5] += c.box; lc[6] += c.tri; }
+                        if (!occ) ps.L = ps.L + sh_contrib;
+                        sh_valid = false;
+                    }
                     float pt_pdf = 1.0f; // uninitialised in the reference when msGGX returns early; defined as 1
                     f3 local_wi = V(0.0f, 1.0f, 0.0f);
                     const f3 brdf = bsdf_sample(P, sf, local_wo, local_wi, pt_pdf, ps.st);
                     const f3 wi = local_to_world(local_wi, t, n, b);
                     const float cosine1 = absdot(wi, n);
                     HitInfo lh;
-                    ray_trace<STATS, HJR_BLOCK>(P, prd.position, wi, lh, stack, lc);
+                    ray_trace<STATS, BLOCK>(P, nodes, tris, prd.position, wi, lh, stack, lc);
                     if (lh.is_hit) {
                         if (lh.is_light) {
                             const float cosine2 = absdot(-wi, lh.normal);
@@ -839,6 +1013,7 @@ __global__ void __launch_bounds__(HJR_BLOCK, HJR_MIN_WAVES) hjr_render_kernel(co
                     }
                 }
 
+                HJR_TICK(3)
                 float pdf = 1.0f;
                 f3 local_wi = V(0.0f, 1.0f, 0.0f);
                 if (INTEGRATOR != HJR_INTEGRATOR_PT_) (void)cmj_2d(ps.st); // drawn and discarded by the reference (rt.h:266, 426)
@@ -848,10 +1023,18 @@ __global__ void __launch_bounds__(HJR_BLOCK, HJR_MIN_WAVES) hjr_render_kernel(co
                 ps.ro = prd.position;
                 ps.rd = wi;
                 ps.depth++;
-                if (ps.depth == 10) end_path(); // MaxDepth (rt.h:166)
+                if (ps.depth == 10) { // MaxDepth (rt.h:166): the path is over, its last shadow ray is still pending
+                    fin_pending = true; fin_L = ps.L;
+                    close_sample();
+                }
+                HJR_TICK(4)
             }
         }
+        HJR_TICK(5)
     }
+#ifdef HJR_TIMING
+    if (lane == 0) for (int i = 0; i < 6; i++) atomicAdd(&P.stats[HJR_NSTAT + i], tk[i]);
+#endif
 
     if (STATS) {
         for (int i = 0; i < HJR_NSTAT; i++) {

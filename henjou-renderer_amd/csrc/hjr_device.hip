@@ -160,7 +160,9 @@ extern "C" int hjr_set_lut(hjr_ctx* c, const uint8_t* rgba, int w, int h)
     return HJR_OK;
 }
 
-#define HJR_BLOCK_LDS 768 /* 12 wavefronts = 3 per SIMD: one workgroup per CU shares the LDS copy of the BVH */
+#ifndef HJR_BLOCK_LDS
+#define HJR_BLOCK_LDS 1024 /* 16 wavefronts = 4 per SIMD (128 VGPRs): one workgroup per CU shares the LDS copy of the BVH; measured 222 ms vs 252 ms at 768 */
+#endif
 #define HJR_LDS_BUDGET (160u * 1024u)
 
 // persistent grid = resident workgroups only: CUs x (workgroups the kernel's VGPR/LDS budget admits per CU), capped by the

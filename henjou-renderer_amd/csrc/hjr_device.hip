@@ -145,6 +145,7 @@ extern "C" int hjr_set_transforms(hjr_ctx* c, const float* m, const float* inv, 
     c->have_frame = true;
     c->stats.bvh_nodes = f.n_nodes;
     c->stats.bvh_depth = f.depth;
+    if (getenv("HJR_VERBOSE")) fprintf(stderr, "[hjr] BVH%d: %u nodes (%zu KB), %u triangles (%zu KB), stack %u entries/lane\n", HJR_BVH_WIDTH, f.n_nodes, f.nodes.size() * 4 / 1024, f.n_tris, f.tri_geom.size() * 4 / 1024, f.stack_need);
     c->stats.n_triangles = f.n_tris;
     return HJR_OK;
 }
@@ -167,20 +168,24 @@ extern "C" int hjr_set_lut(hjr_ctx* c, const uint8_t* rgba, int w, int h)
 
 // persistent grid = resident workgroups only: CUs x (workgroups the kernel's VGPR/LDS budget admits per CU), capped by the
 // number of wavefront-sized batches of work; HJR_BLOCKS_PER_CU overrides the occupancy query
-template <int I, bool S> static int launch(const hjr_ctx* c, const KParams& kp, uint64_t n_items, bool lds_bvh, hipStream_t st)
+// lds_mode: 0 = BVH read from global memory (L2), 1 = BVH staged in LDS with 32-bit stack entries, 2 = with 16-bit entries
+template <int I, bool S, bool S16> static int launch_lds(const hjr_ctx* c, const KParams& kp, uint64_t n_items, hipStream_t st)
 {
-    if (lds_bvh) {
-        const size_t smem = (size_t)HJR_BLOCK_LDS * kp.stack_depth * 4 + ((size_t)kp.n_node_f4 + kp.n_tri_f4) * 16;
-        auto kern = hjr_render_kernel<I, S, HJR_BLOCK_LDS, true>;
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return -1;
-        uint64_t blocks = (uint64_t)c->n_cus;
-        uint64_t max_useful = (n_items + HJR_BLOCK_LDS - 1) / HJR_BLOCK_LDS;
-        if (blocks > max_useful) blocks = max_useful ? max_useful : 1;
-        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(HJR_BLOCK_LDS), smem, st, kp);
-        return 0;
-    }
+    const size_t smem = (((size_t)HJR_BLOCK_LDS * kp.stack_depth * (S16 ? 2 : 4) + 15) / 16) * 16 + ((size_t)kp.n_node_f4 + kp.n_tri_f4) * 16;
+    auto kern = hjr_render_kernel<I, S, HJR_BLOCK_LDS, true, S16>;
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return -1;
+    uint64_t blocks = (uint64_t)c->n_cus;
+    uint64_t max_useful = (n_items + HJR_BLOCK_LDS - 1) / HJR_BLOCK_LDS;
+    if (blocks > max_useful) blocks = max_useful ? max_useful : 1;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(HJR_BLOCK_LDS), smem, st, kp);
+    return 0;
+}
+template <int I, bool S> static int launch(const hjr_ctx* c, const KParams& kp, uint64_t n_items, int lds_mode, hipStream_t st)
+{
+    if (lds_mode == 1) return launch_lds<I, S, false>(c, kp, n_items, st);
+    if (lds_mode == 2) return launch_lds<I, S, true>(c, kp, n_items, st);
     const size_t smem = (size_t)HJR_BLOCK * kp.stack_depth * 4;
-    auto kern = hjr_render_kernel<I, S, HJR_BLOCK, false>;
+    auto kern = hjr_render_kernel<I, S, HJR_BLOCK, false, false>;
     int per_cu = 0;
     if (c->blocks_per_cu > 0) per_cu = c->blocks_per_cu;
     else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, HJR_BLOCK, smem) != hipSuccess || per_cu < 1)
@@ -267,21 +272,23 @@ static int render_impl(hjr_ctx* c, const hjr_params* p, void* d_color, void* d_a
     const bool stats = (p->flags & HJR_FLAG_STATS) != 0;
     kp.n_node_f4 = c->frame.n_nodes * HJR_NODE_F4;
     kp.n_tri_f4 = (c->frame.n_tris ? c->frame.n_tris : 1u) * HJR_TRI_F4;
-    kp.stack_depth = c->frame.depth + 2; // pushes <= depth of the deepest inner node; +1 slack, rounded so that BLOCK * depth % 4 == 0
-    // stage the whole BVH in LDS when it fits beside the traversal stacks of one 768-thread workgroup (HJR_LDS_BVH=0 disables)
-    const size_t lds_need = (size_t)HJR_BLOCK_LDS * kp.stack_depth * 4 + ((size_t)kp.n_node_f4 + kp.n_tri_f4) * 16;
-    bool lds_bvh = lds_need <= HJR_LDS_BUDGET - 1024;
-    if (const char* e = getenv("HJR_LDS_BVH")) lds_bvh = lds_bvh && atoi(e) != 0;
-
+    kp.stack_depth = c->frame.stack_need; // exact worst case for this tree (host/frame.cpp)
+    // stage the whole BVH in LDS when it fits beside the traversal stacks of one HJR_BLOCK_LDS-thread workgroup
+    // (HJR_LDS_BVH=0 disables); 16-bit stack entries (node ids < 32768, leaf-order triangle ids < 8192) when 32-bit ones do not fit
+    const size_t bvh_bytes = ((size_t)kp.n_node_f4 + kp.n_tri_f4) * 16;
+    int lds_mode = 0;
+    if ((size_t)HJR_BLOCK_LDS * kp.stack_depth * 4 + 16 + bvh_bytes <= HJR_LDS_BUDGET - 1024) lds_mode = 1;
+    else if ((size_t)HJR_BLOCK_LDS * kp.stack_depth * 2 + 16 + bvh_bytes <= HJR_LDS_BUDGET - 1024 && c->frame.n_nodes < 32768u && c->frame.n_tris < 8192u) lds_mode = 2;
+    if (const char* e = getenv("HJR_LDS_BVH")) { if (atoi(e) == 0) lds_mode = 0; }
     HIPCHK(hipEventRecord(c->ev0, st));
     int lrc = 0;
     switch (p->integrator * 2 + (stats ? 1 : 0)) {
-    case 0: lrc = launch<HJR_INTEGRATOR_NEE, false>(c, kp, n_items, lds_bvh, st); break;
-    case 1: lrc = launch<HJR_INTEGRATOR_NEE, true>(c, kp, n_items, lds_bvh, st); break;
-    case 2: lrc = launch<HJR_INTEGRATOR_PT, false>(c, kp, n_items, lds_bvh, st); break;
-    case 3: lrc = launch<HJR_INTEGRATOR_PT, true>(c, kp, n_items, lds_bvh, st); break;
-    case 4: lrc = launch<HJR_INTEGRATOR_MIS, false>(c, kp, n_items, lds_bvh, st); break;
-    default: lrc = launch<HJR_INTEGRATOR_MIS, true>(c, kp, n_items, lds_bvh, st); break;
+    case 0: lrc = launch<HJR_INTEGRATOR_NEE, false>(c, kp, n_items, lds_mode, st); break;
+    case 1: lrc = launch<HJR_INTEGRATOR_NEE, true>(c, kp, n_items, lds_mode, st); break;
+    case 2: lrc = launch<HJR_INTEGRATOR_PT, false>(c, kp, n_items, lds_mode, st); break;
+    case 3: lrc = launch<HJR_INTEGRATOR_PT, true>(c, kp, n_items, lds_mode, st); break;
+    case 4: lrc = launch<HJR_INTEGRATOR_MIS, false>(c, kp, n_items, lds_mode, st); break;
+    default: lrc = launch<HJR_INTEGRATOR_MIS, true>(c, kp, n_items, lds_mode, st); break;
     }
     if (lrc != 0) { set_error("hjr_render: could not reserve dynamic LDS for the BVH"); return HJR_ERR_DEVICE; }
     HIPCHK(hipGetLastError());

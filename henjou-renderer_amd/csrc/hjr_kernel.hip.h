@@ -14,6 +14,8 @@
 //
 // Each device function cites the reference lines it restates (paths relative to the reference's include/).
 #pragma once
+#include <type_traits>
+
 #include "hjr_layout.h"
 #include "hjr_math.hip.h"
 
@@ -489,73 +491,145 @@ HD bool ray_tri(f3 v0, f3 v1, f3 v2, f3 o, f3 d, float tmin, float tmax, float& 
     return true;
 }
 
+// ---- per-lane traversal stack in LDS, element i of this lane at stack[i * BLOCK] (conflict-free columns).  Small scenes that
+// are staged into LDS use 16-bit entries (node index < 32768, or leaf: bit15 | count << 13 | first triangle < 8192), which
+// halves the stack's LDS footprint; everything else uses the 32-bit child refs as they are.
+template <typename ST> HD ST stack_enc(uint32_t ref);
+template <> HD uint32_t stack_enc<uint32_t>(uint32_t ref) { return ref; }
+template <> HD uint16_t stack_enc<uint16_t>(uint32_t ref)
+{
+    return (uint16_t)((ref & HJR_LEAF_FLAG) ? (0x8000u | (((ref >> 27) & 3u) << 13) | (ref & 0x1fffu)) : ref);
+}
+HD uint32_t stack_dec(uint32_t r) { return r; }
+HD uint32_t stack_dec(uint16_t r16)
+{
+    const uint32_t r = r16;
+    return (r & 0x8000u) ? (HJR_LEAF_FLAG | (((r >> 13) & 3u) << 27) | (r & 0x1fffu)) : r;
+}
+
+// ---- box-test side of a ray.  The slab test only has to be conservative (boxes are padded): it uses the
+// 1-ulp hardware reciprocal and (plane - o) * inv evaluated as fma(plane, inv, -o * inv).  Direction components smaller than
+// 1e-30 are clamped (sign kept) so that inv stays finite and no inf - inf can appear for axis-parallel rays.
+struct BoxRay {
+    f3 inv, oi;
+#if HJR_BVH_WIDTH == 4
+    uint32_t sx, sy, sz; // 1 when the direction component is negative: near plane row = hi
+#endif
+};
+HD float box_dir(float d) { return (fabsf(d) < 1e-30f) ? copysignf(1e-30f, d) : d; }
+HD BoxRay box_ray(f3 o, f3 d)
+{
+    BoxRay r;
+    const f3 dd = V(box_dir(d.x), box_dir(d.y), box_dir(d.z));
+    r.inv = V(__builtin_amdgcn_rcpf(dd.x), __builtin_amdgcn_rcpf(dd.y), __builtin_amdgcn_rcpf(dd.z));
+    r.oi = V(-o.x * r.inv.x, -o.y * r.inv.y, -o.z * r.inv.z);
+#if HJR_BVH_WIDTH == 4
+    r.sx = dd.x < 0.0f ? 1u : 0u; r.sy = dd.y < 0.0f ? 1u : 0u; r.sz = dd.z < 0.0f ? 1u : 0u;
+#endif
+    return r;
+}
+
+#define HJR_TRAV_DONE 0xffffffffu
+// One inner-node step: tests the children of node `cur` against [tmin, tfar], continues with the nearest hit child, pushes
+// the other hit children, or pops (HJR_TRAV_DONE when the stack is empty).  Returns the number of boxes tested.
+template <int BLOCK, typename ST>
+HD uint32_t node_step(const float4* nodes, uint32_t& cur, const BoxRay& R, float tmin, float tfar, ST* stack, int& sp)
+{
+    const float4* nd = nodes + cur * HJR_NODE_F4;
+#if HJR_BVH_WIDTH == 2
+    const float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
+    const f3 inv = R.inv, oi = R.oi;
+    float t0 = fmaf(q0.x, inv.x, oi.x), t1 = fmaf(q0.w, inv.x, oi.x);
+    float lo0 = fminf(t0, t1), hi0 = fmaxf(t0, t1);
+    t0 = fmaf(q0.y, inv.y, oi.y); t1 = fmaf(q1.x, inv.y, oi.y);
+    lo0 = fmaxf(lo0, fminf(t0, t1)); hi0 = fminf(hi0, fmaxf(t0, t1));
+    t0 = fmaf(q0.z, inv.z, oi.z); t1 = fmaf(q1.y, inv.z, oi.z);
+    lo0 = fmaxf(lo0, fminf(t0, t1)); hi0 = fminf(hi0, fmaxf(t0, t1));
+    lo0 = fmaxf(lo0, tmin); hi0 = fminf(hi0, tfar);
+    t0 = fmaf(q1.z, inv.x, oi.x); t1 = fmaf(q2.y, inv.x, oi.x);
+    float lo1 = fminf(t0, t1), hi1 = fmaxf(t0, t1);
+    t0 = fmaf(q1.w, inv.y, oi.y); t1 = fmaf(q2.z, inv.y, oi.y);
+    lo1 = fmaxf(lo1, fminf(t0, t1)); hi1 = fminf(hi1, fmaxf(t0, t1));
+    t0 = fmaf(q2.x, inv.z, oi.z); t1 = fmaf(q2.w, inv.z, oi.z);
+    lo1 = fmaxf(lo1, fminf(t0, t1)); hi1 = fminf(hi1, fmaxf(t0, t1));
+    lo1 = fmaxf(lo1, tmin); hi1 = fminf(hi1, tfar);
+    const bool h0 = lo0 <= hi0 * 1.0000004f, h1 = lo1 <= hi1 * 1.0000004f;
+    const uint32_t c0 = f2bits(q3.x), c1 = f2bits(q3.y);
+    if (h0 && h1) {
+        const bool swap = lo1 < lo0;
+        stack[sp * BLOCK] = stack_enc<ST>(swap ? c0 : c1);
+        sp++;
+        cur = swap ? c1 : c0;
+    } else if (h0) cur = c0;
+    else if (h1) cur = c1;
+    else if (sp > 0) { sp--; cur = stack_dec(stack[sp * BLOCK]); }
+    else cur = HJR_TRAV_DONE;
+    return 2u;
+#else
+    // near / far plane rows picked by the ray's direction signs: no min/max per axis
+    const float4 nx = nd[0 + R.sx], fx = nd[1 - R.sx];
+    const float4 ny = nd[2 + R.sy], fy = nd[3 - R.sy];
+    const float4 nz = nd[4 + R.sz], fz = nd[5 - R.sz];
+    const float4 rr = nd[6];
+    const f3 inv = R.inv, oi = R.oi;
+    const float INF = bits2f(0x7f800000u);
+#define HJR_CHILD(c, C)                                                                                                  \
+    float tn##C = fmaxf(fmaxf(fmaf(nx.c, inv.x, oi.x), fmaf(ny.c, inv.y, oi.y)), fmaxf(fmaf(nz.c, inv.z, oi.z), tmin)); \
+    const float tf##C = fminf(fminf(fmaf(fx.c, inv.x, oi.x), fmaf(fy.c, inv.y, oi.y)), fminf(fmaf(fz.c, inv.z, oi.z), tfar)); \
+    const bool h##C = tn##C <= tf##C;                                                                                   \
+    tn##C = h##C ? tn##C : INF;
+    HJR_CHILD(x, 0) HJR_CHILD(y, 1) HJR_CHILD(z, 2) HJR_CHILD(w, 3)
+#undef HJR_CHILD
+    const uint32_t r0 = f2bits(rr.x), r1 = f2bits(rr.y), r2 = f2bits(rr.z), r3 = f2bits(rr.w);
+    const float m = fminf(fminf(tn0, tn1), fminf(tn2, tn3));
+    // nearest hit child first (ties: lowest slot); the other hit children are pushed in slot order
+    const int sel = (tn0 == m) ? 0 : ((tn1 == m) ? 1 : ((tn2 == m) ? 2 : 3));
+    if (h3 && sel != 3) { stack[sp * BLOCK] = stack_enc<ST>(r3); sp++; }
+    if (h2 && sel != 2) { stack[sp * BLOCK] = stack_enc<ST>(r2); sp++; }
+    if (h1 && sel != 1) { stack[sp * BLOCK] = stack_enc<ST>(r1); sp++; }
+    if (h0 && sel != 0) { stack[sp * BLOCK] = stack_enc<ST>(r0); sp++; }
+    if (h0 || h1 || h2 || h3) cur = (sel == 0) ? r0 : ((sel == 1) ? r1 : ((sel == 2) ? r2 : r3));
+    else if (sp > 0) { sp--; cur = stack_dec(stack[sp * BLOCK]); }
+    else cur = HJR_TRAV_DONE;
+    return 4u;
+#endif
+}
+
 struct Hit { float t, b1, b2; uint32_t k, prim; };
 
 // stack: this lane's column of the LDS stack, element i at stack[i * BLOCK]
-template <bool ANY, bool STATS, int BLOCK>
-HD bool traverse(const float4* nodes, const float4* tris, f3 o, f3 d, float tmin, float tmax, Hit& hit, uint32_t* stack, Counters& cnt)
+template <bool ANY, bool STATS, int BLOCK, typename ST>
+HD bool traverse(const float4* nodes, const float4* tris, f3 o, f3 d, float tmin, float tmax, Hit& hit, ST* stack, Counters& cnt)
 {
-    // The slab test only has to be conservative (boxes are padded), so it may use the 1-ulp hardware
-    // reciprocal and fused (lo - o) * inv = fma(lo, inv, -o * inv); the triangle test below is the bit-defined part.
-    const f3 inv = V(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
-    const f3 oi = V(-o.x * inv.x, -o.y * inv.y, -o.z * inv.z);
+    const BoxRay R = box_ray(o, d);
     int sp = 0;
     uint32_t cur = 0;
     hit.prim = 0xffffffffu;
     hit.t = tmax;
     for (;;) {
-        if (!(cur & HJR_LEAF_FLAG)) {
-            const float4* nd = nodes + cur * HJR_NODE_F4;
-            const float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
-            const float tfar = hit.t;
-            // child 0: lo (q0.x q0.y q0.z) hi (q0.w q1.x q1.y)
-            float t0 = fmaf(q0.x, inv.x, oi.x), t1 = fmaf(q0.w, inv.x, oi.x);
-            float lo0 = fminf(t0, t1), hi0 = fmaxf(t0, t1);
-            t0 = fmaf(q0.y, inv.y, oi.y); t1 = fmaf(q1.x, inv.y, oi.y);
-            lo0 = fmaxf(lo0, fminf(t0, t1)); hi0 = fminf(hi0, fmaxf(t0, t1));
-            t0 = fmaf(q0.z, inv.z, oi.z); t1 = fmaf(q1.y, inv.z, oi.z);
-            lo0 = fmaxf(lo0, fminf(t0, t1)); hi0 = fminf(hi0, fmaxf(t0, t1));
-            lo0 = fmaxf(lo0, tmin); hi0 = fminf(hi0, tfar);
-            // child 1: lo (q1.z q1.w q2.x) hi (q2.y q2.z q2.w)
-            t0 = fmaf(q1.z, inv.x, oi.x); t1 = fmaf(q2.y, inv.x, oi.x);
-            float lo1 = fminf(t0, t1), hi1 = fmaxf(t0, t1);
-            t0 = fmaf(q1.w, inv.y, oi.y); t1 = fmaf(q2.z, inv.y, oi.y);
-            lo1 = fmaxf(lo1, fminf(t0, t1)); hi1 = fminf(hi1, fmaxf(t0, t1));
-            t0 = fmaf(q2.x, inv.z, oi.z); t1 = fmaf(q2.w, inv.z, oi.z);
-            lo1 = fmaxf(lo1, fminf(t0, t1)); hi1 = fminf(hi1, fmaxf(t0, t1));
-            lo1 = fmaxf(lo1, tmin); hi1 = fminf(hi1, tfar);
-            const bool h0 = lo0 <= hi0 * 1.0000004f, h1 = lo1 <= hi1 * 1.0000004f;
-            const uint32_t c0 = f2bits(q3.x), c1 = f2bits(q3.y);
-            if (STATS) cnt.box += 2;
-            if (h0 && h1) {
-                const bool swap = lo1 < lo0;
-                stack[sp * BLOCK] = swap ? c0 : c1;
-                sp++;
-                cur = swap ? c1 : c0;
-                continue;
-            }
-            if (h0) { cur = c0; continue; }
-            if (h1) { cur = c1; continue; }
-        } else {
-            const uint32_t first = cur & 0x07ffffffu, count = (cur >> 27) & 15u;
-            for (uint32_t i = 0; i < count; i++) {
-                const float4* g = tris + (first + i) * HJR_TRI_F4;
-                const float4 g0 = g[0], g1 = g[1], g2 = g[2];
-                float t, b1, b2;
-                if (STATS) cnt.tri++;
-                if (ray_tri(V(g0.x, g0.y, g0.z), V(g0.w, g1.x, g1.y), V(g1.z, g1.w, g2.x), o, d, tmin, tmax, t, b1, b2)) {
-                    if (ANY) return true;
-                    const uint32_t prim = f2bits(g2.y);
-                    // order-independent closest-hit rule: smaller t wins; equal t -> smaller global prim id
-                    if (hit.prim == 0xffffffffu || t < hit.t || (t == hit.t && prim < hit.prim)) {
-                        hit.t = t; hit.b1 = b1; hit.b2 = b2; hit.k = first + i; hit.prim = prim;
-                    }
+        while (!(cur & HJR_LEAF_FLAG)) { // descend through inner nodes until this lane holds a leaf (or is done)
+            const uint32_t nb = node_step<BLOCK, ST>(nodes, cur, R, tmin, hit.t, stack, sp);
+            if (STATS) cnt.box += nb;
+        }
+        if (cur == HJR_TRAV_DONE) break;
+        const uint32_t first = cur & 0x07ffffffu, count = (cur >> 27) & 15u;
+        for (uint32_t i = 0; i < count; i++) {
+            const float4* g = tris + (first + i) * HJR_TRI_F4;
+            const float4 g0 = g[0], g1 = g[1], g2 = g[2];
+            float t, b1, b2;
+            if (STATS) cnt.tri++;
+            if (ray_tri(V(g0.x, g0.y, g0.z), V(g0.w, g1.x, g1.y), V(g1.z, g1.w, g2.x), o, d, tmin, tmax, t, b1, b2)) {
+                if (ANY) return true;
+                const uint32_t prim = f2bits(g2.y);
+                // order-independent closest-hit rule: smaller t wins; equal t -> smaller global prim id
+                if (hit.prim == 0xffffffffu || t < hit.t || (t == hit.t && prim < hit.prim)) {
+                    hit.t = t; hit.b1 = b1; hit.b2 = b2; hit.k = first + i; hit.prim = prim;
                 }
             }
         }
         if (sp == 0) break;
         sp--;
-        cur = stack[sp * BLOCK];
+        cur = stack_dec(stack[sp * BLOCK]);
     }
     return hit.prim != 0xffffffffu;
 }
@@ -565,10 +639,9 @@ HD bool traverse(const float4* nodes, const float4* tris, f3 o, f3 d, float tmin
 // resolved, without waiting for the rest of the wave, so the wave's trip count is max_lanes(tripsA + tripsB) instead of
 // max(tripsA) + max(tripsB) — the SIMT cost of per-lane trip-count variance drops by ~1/3 (profiles/r01_experiments.md).
 // Results are identical to two separate traversals.
-#define HJR_TRAV_DONE 0xffffffffu
-template <bool STATS, int BLOCK>
+template <bool STATS, int BLOCK, typename ST>
 HD void traverse_fused(const float4* nodes, const float4* tris, const bool a_valid, const f3 ao, const f3 ad, const float a_tmax, const bool b_valid,
-                       const f3 bo, const f3 bd, bool& occluded, Hit& hit, uint32_t* stack, Counters& ca, Counters& cb)
+                       const f3 bo, const f3 bd, bool& occluded, Hit& hit, ST* stack, Counters& ca, Counters& cb)
 {
     const float tmin = 0.001f;
     occluded = false;
@@ -577,43 +650,15 @@ HD void traverse_fused(const float4* nodes, const float4* tris, const bool a_val
     int phase = a_valid ? 0 : (b_valid ? 1 : 2);
     f3 o = (phase == 0) ? ao : bo;
     f3 d = (phase == 0) ? ad : bd;
-    // conservative slab test: hardware reciprocal + fma (boxes are padded)
-    f3 inv = V(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
-    f3 oi = V(-o.x * inv.x, -o.y * inv.y, -o.z * inv.z);
+    BoxRay R = box_ray(o, d);
     int sp = 0;
     uint32_t cur = (phase < 2) ? 0u : HJR_TRAV_DONE;
     while (phase < 2) {
         // "while-while" traversal: every lane first descends through inner nodes until it holds a leaf (or is out of work) ...
         while (!(cur & HJR_LEAF_FLAG)) {
-            const float4* nd = nodes + cur * HJR_NODE_F4;
-            const float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
             const float tfar = (phase == 0) ? a_tmax : hit.t;
-            float t0 = fmaf(q0.x, inv.x, oi.x), t1 = fmaf(q0.w, inv.x, oi.x);
-            float lo0 = fminf(t0, t1), hi0 = fmaxf(t0, t1);
-            t0 = fmaf(q0.y, inv.y, oi.y); t1 = fmaf(q1.x, inv.y, oi.y);
-            lo0 = fmaxf(lo0, fminf(t0, t1)); hi0 = fminf(hi0, fmaxf(t0, t1));
-            t0 = fmaf(q0.z, inv.z, oi.z); t1 = fmaf(q1.y, inv.z, oi.z);
-            lo0 = fmaxf(lo0, fminf(t0, t1)); hi0 = fminf(hi0, fmaxf(t0, t1));
-            lo0 = fmaxf(lo0, tmin); hi0 = fminf(hi0, tfar);
-            t0 = fmaf(q1.z, inv.x, oi.x); t1 = fmaf(q2.y, inv.x, oi.x);
-            float lo1 = fminf(t0, t1), hi1 = fmaxf(t0, t1);
-            t0 = fmaf(q1.w, inv.y, oi.y); t1 = fmaf(q2.z, inv.y, oi.y);
-            lo1 = fmaxf(lo1, fminf(t0, t1)); hi1 = fminf(hi1, fmaxf(t0, t1));
-            t0 = fmaf(q2.x, inv.z, oi.z); t1 = fmaf(q2.w, inv.z, oi.z);
-            lo1 = fmaxf(lo1, fminf(t0, t1)); hi1 = fminf(hi1, fmaxf(t0, t1));
-            lo1 = fmaxf(lo1, tmin); hi1 = fminf(hi1, tfar);
-            const bool h0 = lo0 <= hi0 * 1.0000004f, h1 = lo1 <= hi1 * 1.0000004f;
-            const uint32_t c0 = f2bits(q3.x), c1 = f2bits(q3.y);
-            if (STATS) { if (phase == 0) ca.box += 2; else cb.box += 2; }
-            if (h0 && h1) {
-                const bool swap = lo1 < lo0;
-                stack[sp * BLOCK] = swap ? c0 : c1;
-                sp++;
-                cur = swap ? c1 : c0;
-            } else if (h0) cur = c0;
-            else if (h1) cur = c1;
-            else if (sp > 0) { sp--; cur = stack[sp * BLOCK]; }
-            else cur = HJR_TRAV_DONE;
+            const uint32_t nb = node_step<BLOCK, ST>(nodes, cur, R, tmin, tfar, stack, sp);
+            if (STATS) { if (phase == 0) ca.box += nb; else cb.box += nb; }
         }
         // ... then all lanes test their leaf's triangles together
         bool done = (cur == HJR_TRAV_DONE);
@@ -635,7 +680,7 @@ HD void traverse_fused(const float4* nodes, const float4* tris, const bool a_val
                 }
             }
             if (!done) {
-                if (sp > 0) { sp--; cur = stack[sp * BLOCK]; }
+                if (sp > 0) { sp--; cur = stack_dec(stack[sp * BLOCK]); }
                 else done = true;
             }
         }
@@ -643,8 +688,7 @@ HD void traverse_fused(const float4* nodes, const float4* tris, const bool a_val
             if (phase == 0 && b_valid) { // this lane's shadow ray is resolved: start its closest-hit ray right away
                 phase = 1;
                 o = bo; d = bd;
-                inv = V(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
-                oi = V(-o.x * inv.x, -o.y * inv.y, -o.z * inv.z);
+                R = box_ray(o, d);
                 sp = 0; cur = 0;
             } else { phase = 2; cur = HJR_TRAV_DONE; }
         }
@@ -697,12 +741,12 @@ HD void hit_program(const KParams& P, const float4* tris, const Hit& h, HitInfo&
 }
 
 // RayTrace (rt.h:43-69): stand-alone closest-hit query (used by MIS' BSDF-sampled light ray)
-template <bool STATS, int BLOCK>
-HD void ray_trace(const KParams& P, const float4* nodes, const float4* tris, f3 o, f3 d, HitInfo& prd, uint32_t* stack, unsigned long long* lc)
+template <bool STATS, int BLOCK, typename ST>
+HD void ray_trace(const KParams& P, const float4* nodes, const float4* tris, f3 o, f3 d, HitInfo& prd, ST* stack, unsigned long long* lc)
 {
     Hit h;
     Counters c; c.box = 0; c.tri = 0;
-    traverse<false, STATS, BLOCK>(nodes, tris, o, d, 0.001f, 1e16f, h, stack, c);
+    traverse<false, STATS, BLOCK, ST>(nodes, tris, o, d, 0.001f, 1e16f, h, stack, c);
     if (STATS) { lc[1] += 1; lc[3] += c.box; lc[4] += c.tri; }
     hit_program<STATS>(P, tris, h, prd, lc);
 }
@@ -769,15 +813,16 @@ HD void start_path(const KParams& P, PathState& ps, uint32_t px, uint32_t py, ui
 // workgroup of BLOCK threads per CU shares the copy.  Chosen by the host when the scene fits (hjr_device.hip).
 extern __shared__ float4 hjr_smem[];
 
-template <int INTEGRATOR, bool STATS, int BLOCK, bool LDSBVH>
+template <int INTEGRATOR, bool STATS, int BLOCK, bool LDSBVH, bool STACK16>
 __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_render_kernel(const KParams P)
 {
-    uint32_t* stack = reinterpret_cast<uint32_t*>(hjr_smem) + threadIdx.x;
+    typedef typename std::conditional<STACK16, uint16_t, uint32_t>::type ST; // stack entry type
+    ST* stack = reinterpret_cast<ST*>(hjr_smem) + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
     const float4* nodes = P.nodes;
     const float4* tris = P.tri_geom;
     if (LDSBVH) {
-        float4* l_nodes = hjr_smem + (BLOCK * P.stack_depth) / 4u;
+        float4* l_nodes = hjr_smem + (BLOCK * P.stack_depth * (uint32_t)sizeof(ST) + 15u) / 16u;
         float4* l_tris = l_nodes + P.n_node_f4;
         for (uint32_t i = threadIdx.x; i < P.n_node_f4; i += BLOCK) l_nodes[i] = P.nodes[i];
         for (uint32_t i = threadIdx.x; i < P.n_tri_f4; i += BLOCK) l_tris[i] = P.tri_geom[i];
@@ -893,7 +938,7 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
         Hit h;
         {
             Counters ca, cb; ca.box = ca.tri = cb.box = cb.tri = 0;
-            traverse_fused<STATS, BLOCK>(nodes, tris, sh_valid, sh_o, sh_d, sh_tmax, tracing, ps.ro, ps.rd, occluded, h, stack, ca, cb);
+            traverse_fused<STATS, BLOCK, ST>(nodes, tris, sh_valid, sh_o, sh_d, sh_tmax, tracing, ps.ro, ps.rd, occluded, h, stack, ca, cb);
             if (STATS) {
                 if (sh_valid) { lc[2] += 1; lc[5] += ca.box; lc[6] += ca.tri; }
                 if (tracing) { lc[1] += 1; lc[3] += cb.box; lc[4] += cb.tri; }
@@ -971,7 +1016,7 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
                     if (sh_valid) {
                         Hit shh;
                         Counters c; c.box = 0; c.tri = 0;
-                        const bool occ = traverse<true, STATS, BLOCK>(nodes, tris, sh_o, sh_d, 0.001f, sh_tmax, shh, stack, c);
+                        const bool occ = traverse<true, STATS, BLOCK, ST>(nodes, tris, sh_o, sh_d, 0.001f, sh_tmax, shh, stack, c);
                         if (STATS) { lc[2] += 1; lc[5] += c.box; lc[6] += c.tri; }
                         if (!occ) ps.L = ps.L + sh_contrib;
                         sh_valid = false;
@@ -982,7 +1027,7 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
                     const f3 wi = local_to_world(local_wi, t, n, b);
                     const float cosine1 = absdot(wi, n);
                     HitInfo lh;
-                    ray_trace<STATS, BLOCK>(P, nodes, tris, prd.position, wi, lh, stack, lc);
+                    ray_trace<STATS, BLOCK, ST>(P, nodes, tris, prd.position, wi, lh, stack, lc);
                     if (lh.is_hit) {
                         if (lh.is_light) {
                             const float cosine2 = absdot(-wi, lh.normal);

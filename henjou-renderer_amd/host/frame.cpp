@@ -246,9 +246,17 @@ bool build_frame(const SceneCopy& sc, const float* M, const float* Mi, uint32_t 
     out.tri_geom.assign((size_t)std::max(n, 1u) * HJR_TRI_F4 * 4, 0.0f);
     auto leaf_ref = [](uint32_t first, uint32_t count) { return HJR_LEAF_FLAG | (count << 27) | first; };
     if (n == 0) {
-        out.nodes.assign(16, 0.0f);
+        out.nodes.assign((size_t)HJR_NODE_F4 * 4, 0.0f);
+#if HJR_BVH_WIDTH == 2
         out.nodes[12] = u2f(leaf_ref(0, 0)); out.nodes[13] = u2f(leaf_ref(0, 0));
+#else
+        for (int c = 0; c < 4; c++) {
+            for (int a = 0; a < 3; a++) { out.nodes[8 * a + c] = 1e30f; out.nodes[8 * a + 4 + c] = -1e30f; }
+            out.nodes[24 + c] = u2f(leaf_ref(0, 0));
+        }
+#endif
         out.n_nodes = 1;
+        out.stack_need = 2;
         return true;
     }
     B.nodes.reserve((size_t)2 * n);
@@ -261,6 +269,7 @@ bool build_frame(const SceneCopy& sc, const float* M, const float* Mi, uint32_t 
         memcpy(g, &wv[9 * (size_t)t], 9 * sizeof(float));
         g[9] = u2f(t);
     }
+#if HJR_BVH_WIDTH == 2
     // emit inner nodes depth-first; a root that is itself a leaf (n == 1) gets an empty sibling
     std::vector<int> inner_id(B.nodes.size(), -1);
     uint32_t n_inner = 0;
@@ -273,10 +282,12 @@ bool build_frame(const SceneCopy& sc, const float* M, const float* Mi, uint32_t 
         q[6] = r.box.lo[0]; q[7] = r.box.lo[1]; q[8] = r.box.lo[2]; q[9] = r.box.hi[0]; q[10] = r.box.hi[1]; q[11] = r.box.hi[2];
         q[12] = u2f(leaf_ref(r.first, r.count)); q[13] = u2f(leaf_ref(0, 0));
         out.n_nodes = 1;
+        out.stack_need = 2;
         return true;
     }
     out.nodes.assign((size_t)n_inner * 16, 0.0f);
     out.n_nodes = n_inner;
+    out.stack_need = B.max_depth + 2;
     for (size_t i = 0; i < B.nodes.size(); i++) {
         if (inner_id[i] < 0) continue;
         float* q = &out.nodes[(size_t)inner_id[i] * 16];
@@ -288,6 +299,69 @@ bool build_frame(const SceneCopy& sc, const float* M, const float* Mi, uint32_t 
             q[12 + c] = u2f(ref);
         }
     }
+#else
+    // collapse the BVH2 into a BVH4: a wide node starts from the two children of a BVH2 inner node and repeatedly replaces its
+    // largest-area inner child by that child's two children until it has four children (or only leaves)
+    struct Wide { int child[4]; int n; };
+    std::vector<Wide> wide;
+    std::vector<int> wide_of(B.nodes.size(), -1); // BVH2 inner node -> wide node id
+    auto make_wide = [&](int root2) {
+        Wide w; w.n = 0;
+        if (B.nodes[(size_t)root2].left < 0) { w.child[w.n++] = root2; } // a single leaf (n == 1): wide root with one leaf child
+        else { w.child[w.n++] = B.nodes[(size_t)root2].left; w.child[w.n++] = B.nodes[(size_t)root2].right; }
+        while (w.n < 4) {
+            int best = -1; float barea = -1.0f;
+            for (int c = 0; c < w.n; c++) {
+                const BuildNode& ch = B.nodes[(size_t)w.child[c]];
+                if (ch.left >= 0 && ch.box.area() > barea) { barea = ch.box.area(); best = c; }
+            }
+            if (best < 0) break;
+            int e = w.child[best];
+            w.child[best] = B.nodes[(size_t)e].left;
+            w.child[w.n++] = B.nodes[(size_t)e].right;
+        }
+        wide_of[(size_t)root2] = (int)wide.size();
+        wide.push_back(w);
+        return (int)wide.size() - 1;
+    };
+    make_wide(0);
+    for (size_t head = 0; head < wide.size(); head++) { // breadth-first: the top of the tree is contiguous
+        for (int c = 0; c < wide[head].n; c++) {
+            int ch = wide[head].child[c];
+            if (B.nodes[(size_t)ch].left >= 0) make_wide(ch);
+        }
+    }
+    out.n_nodes = (uint32_t)wide.size();
+    out.nodes.assign(wide.size() * (size_t)HJR_NODE_F4 * 4, 0.0f);
+    for (size_t i = 0; i < wide.size(); i++) {
+        float* q = &out.nodes[i * (size_t)HJR_NODE_F4 * 4];
+        for (int c = 0; c < 4; c++) {
+            if (c < wide[i].n) {
+                const BuildNode& ch = B.nodes[(size_t)wide[i].child[c]];
+                for (int a = 0; a < 3; a++) { q[8 * a + c] = ch.box.lo[a]; q[8 * a + 4 + c] = ch.box.hi[a]; }
+                uint32_t ref = (ch.left >= 0) ? (uint32_t)wide_of[(size_t)wide[i].child[c]] : leaf_ref(ch.first, ch.count);
+                q[24 + c] = u2f(ref);
+            } else {
+                for (int a = 0; a < 3; a++) { q[8 * a + c] = 1e30f; q[8 * a + 4 + c] = -1e30f; }
+                q[24 + c] = u2f(leaf_ref(0, 0));
+            }
+        }
+    }
+    // exact worst-case traversal stack: every visited wide node can leave (children - 1) entries pending
+    {
+        std::vector<uint32_t> pend(wide.size(), 0);
+        uint32_t worst = 1;
+        for (size_t i = 0; i < wide.size(); i++) { // parents precede children (breadth-first ids)
+            uint32_t here = pend[i] + (uint32_t)(wide[i].n > 0 ? wide[i].n - 1 : 0);
+            worst = std::max(worst, here);
+            for (int c = 0; c < wide[i].n; c++) {
+                int ch = wide[i].child[c];
+                if (B.nodes[(size_t)ch].left >= 0) pend[(size_t)wide_of[(size_t)ch]] = here;
+            }
+        }
+        out.stack_need = worst + 1;
+    }
+#endif
     return true;
 }
 

@@ -19,6 +19,7 @@ struct FrameData {
     std::vector<uint32_t> tri_inst;// instance id per global prim
     std::vector<float> lights;     // HJR_LIGHT_F4 float4 per emissive triangle
     uint32_t n_tris = 0, n_nodes = 0, n_lights = 0, depth = 0;
+    uint32_t stack_need = 2; // worst-case traversal stack entries per lane for this tree
 };
 
 // Owning copy of an hjr_scene_view (cpySceneDataToDevice keeps the host vectors alive too, renderer.h:197-255).

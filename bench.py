@@ -46,6 +46,10 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=256)
     ap.add_argument("--integrator", default="NEE", choices=["NEE", "Pathtrace", "MIS"])
+    ap.add_argument("--scene", default="cornell", choices=["cornell", "thinfilm", "ior15", "stress"],
+                    help="cornell = BASELINE configs[1] (the headline); thinfilm / ior15 = configs[2] / [3]; stress = generated ~1 M-triangle scene")
+    ap.add_argument("--stress-spheres", type=int, default=64)
+    ap.add_argument("--stress-segments", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-spp", type=int, default=4, help="spp of the bounded CPU-baseline sample")
     args = ap.parse_args()
@@ -76,7 +80,15 @@ def main():
     os.chdir(hjr.ASSETS)
     try:
         r = hjr.Renderer(local_rank)
-        r.loadRenderOption("render_option_c2.json")
+        config = {"cornell": "render_option_c2.json", "thinfilm": "render_option_c3.json", "ior15": "render_option_c4.json"}.get(args.scene)
+        if args.scene == "stress":
+            import subprocess
+            import tempfile
+            sdir = os.path.join(tempfile.gettempdir(), "hjr_stress_%d_%d_r%d" % (args.stress_spheres, args.stress_segments, rank))
+            subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_stress_scene.py"), sdir, "--spheres",
+                                   str(args.stress_spheres), "--segments", str(args.stress_segments)], stdout=subprocess.DEVNULL)
+            config = os.path.join(sdir, "render_option_stress.json")
+        r.loadRenderOption(config)
         r.render_option.image_width, r.render_option.image_height, r.render_option.max_spp = W, H, SPP
         r.render_option.integrator = integ
         r.loadGLTFfile(r.render_option.gltf_path.decode(), r.render_option.gltf_name.decode())
@@ -130,8 +142,9 @@ def main():
         "scaling": "strong",
         "vs_baseline": None,
         "dtype": "f32",
-        "data": "synthetic (bundled cornelbox.gltf, 984 triangles; CMJ sample streams from a fixed seed)",
-        "config": {"workload": "BASELINE configs[1]: cornelbox.gltf %dx%d %d spp, %s integrator" % (W, H, SPP, args.integrator),
+        "data": "synthetic (%s, %d triangles; CMJ sample streams from a fixed seed)" % (r.render_option.gltf_name.decode(), r.scene.view.n_triangles),
+        "config": {"workload": "%s: %s %dx%d %d spp, %s integrator" % ({"cornell": "BASELINE configs[1]", "thinfilm": "BASELINE configs[2]", "ior15": "BASELINE configs[3]", "stress": "synthetic stress scene"}[args.scene], r.render_option.gltf_name.decode(), W, H, SPP, args.integrator),
+                   "scene": args.scene, "triangles": int(r.scene.view.n_triangles),
                    "width": W, "height": H, "spp": SPP, "integrator": args.integrator,
                    "parallelism": "8x8 pixel tiles round-robin over %d GPU(s)%s" % (world, " + RCCL reduce of the float4 framebuffer" if world > 1 else "")},
     }
@@ -152,7 +165,7 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("%dx%dx%d_%s_n%d" % (W, H, SPP, args.integrator, world))
+                traffic = json.load(open(tpath)).get("%s_%dx%dx%d_%s_n%d" % (args.scene, W, H, SPP, args.integrator, world))
             except Exception:
                 traffic = None
         out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -132,7 +132,9 @@ extern "C" int hjr_set_transforms(hjr_ctx* c, const float* m, const float* inv, 
     if (!c || (n && (!m || !inv))) { set_error("hjr_set_transforms: null argument"); return HJR_ERR_ARG; }
     if (!c->have_scene) { set_error("hjr_set_transforms: no scene uploaded"); return HJR_ERR_STATE; }
     std::string err;
-    if (!hjr::build_frame(c->scene, m, inv, n, c->frame, err)) { set_error("hjr_set_transforms: " + err); return HJR_ERR_ARG; }
+    bool allow_lds = true;
+    if (const char* e = getenv("HJR_LDS_BVH")) allow_lds = atoi(e) != 0;
+    if (!hjr::build_frame(c->scene, m, inv, n, allow_lds, c->frame, err)) { set_error("hjr_set_transforms: " + err); return HJR_ERR_ARG; }
     HIPCHK(hipSetDevice(c->device));
     const hjr::FrameData& f = c->frame;
     bool ok = c->d_nodes.upload(f.nodes.data(), f.nodes.size() * 4, c->stream) &&
@@ -145,7 +147,7 @@ extern "C" int hjr_set_transforms(hjr_ctx* c, const float* m, const float* inv, 
     c->have_frame = true;
     c->stats.bvh_nodes = f.n_nodes;
     c->stats.bvh_depth = f.depth;
-    if (getenv("HJR_VERBOSE")) fprintf(stderr, "[hjr] BVH%d: %u nodes (%zu KB), %u triangles (%zu KB), stack %u entries/lane\n", HJR_BVH_WIDTH, f.n_nodes, f.nodes.size() * 4 / 1024, f.n_tris, f.tri_geom.size() * 4 / 1024, f.stack_need);
+    if (getenv("HJR_VERBOSE")) fprintf(stderr, "[hjr] BVH%u (lds_mode %d): %u nodes (%zu KB), %u triangles (%zu KB), stack %u entries/lane\n", f.width, f.lds_mode, f.n_nodes, f.nodes.size() * 4 / 1024, f.n_tris, f.tri_geom.size() * 4 / 1024, f.stack_need);
     c->stats.n_triangles = f.n_tris;
     return HJR_OK;
 }
@@ -161,18 +163,15 @@ extern "C" int hjr_set_lut(hjr_ctx* c, const uint8_t* rgba, int w, int h)
     return HJR_OK;
 }
 
-#ifndef HJR_BLOCK_LDS
-#define HJR_BLOCK_LDS 1024 /* 16 wavefronts = 4 per SIMD (128 VGPRs): one workgroup per CU shares the LDS copy of the BVH; measured 222 ms vs 252 ms at 768 */
-#endif
-#define HJR_LDS_BUDGET (160u * 1024u)
 
 // persistent grid = resident workgroups only: CUs x (workgroups the kernel's VGPR/LDS budget admits per CU), capped by the
 // number of wavefront-sized batches of work; HJR_BLOCKS_PER_CU overrides the occupancy query
-// lds_mode: 0 = BVH read from global memory (L2), 1 = BVH staged in LDS with 32-bit stack entries, 2 = with 16-bit entries
+template <int I, bool S, int W> static int launch_mem(const hjr_ctx* c, const KParams& kp, uint64_t n_items, hipStream_t st);
+// lds_mode: 0 = BVH4 read from memory, 1 = BVH2 staged in LDS with 32-bit stack entries, 2 = with 16-bit entries, 3 = BVH2 from memory
 template <int I, bool S, bool S16> static int launch_lds(const hjr_ctx* c, const KParams& kp, uint64_t n_items, hipStream_t st)
 {
     const size_t smem = (((size_t)HJR_BLOCK_LDS * kp.stack_depth * (S16 ? 2 : 4) + 15) / 16) * 16 + ((size_t)kp.n_node_f4 + kp.n_tri_f4) * 16;
-    auto kern = hjr_render_kernel<I, S, HJR_BLOCK_LDS, true, S16>;
+    auto kern = hjr_render_kernel<I, S, HJR_BLOCK_LDS, true, S16, 2>;
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return -1;
     uint64_t blocks = (uint64_t)c->n_cus;
     uint64_t max_useful = (n_items + HJR_BLOCK_LDS - 1) / HJR_BLOCK_LDS;
@@ -184,8 +183,13 @@ template <int I, bool S> static int launch(const hjr_ctx* c, const KParams& kp, 
 {
     if (lds_mode == 1) return launch_lds<I, S, false>(c, kp, n_items, st);
     if (lds_mode == 2) return launch_lds<I, S, true>(c, kp, n_items, st);
+    if (lds_mode == 3) return launch_mem<I, S, 2>(c, kp, n_items, st); // BVH2 read from memory (HJR_BVH_WIDTH=2 knob on a big scene)
+    return launch_mem<I, S, 4>(c, kp, n_items, st);
+}
+template <int I, bool S, int W> static int launch_mem(const hjr_ctx* c, const KParams& kp, uint64_t n_items, hipStream_t st)
+{
     const size_t smem = (size_t)HJR_BLOCK * kp.stack_depth * 4;
-    auto kern = hjr_render_kernel<I, S, HJR_BLOCK, false, false>;
+    auto kern = hjr_render_kernel<I, S, HJR_BLOCK, false, false, W>;
     int per_cu = 0;
     if (c->blocks_per_cu > 0) per_cu = c->blocks_per_cu;
     else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, HJR_BLOCK, smem) != hipSuccess || per_cu < 1)
@@ -215,7 +219,7 @@ static int render_impl(hjr_ctx* c, const hjr_params* p, void* d_color, void* d_a
     if (n_items >= 0xffffffffull) { set_error("hjr_render: image too large"); return HJR_ERR_ARG; }
 
     // work area: [0] queue head, [16..] HJR_NSTAT uint64 counters
-    const size_t work_bytes = 16 + (HJR_NSTAT + 6) * 8; // +6: phase clocks of the HJR_TIMING diagnostic build
+    const size_t work_bytes = 16 + (HJR_NSTAT + 8) * 8; // +8: phase clocks of the HJR_TIMING diagnostic build
     if (c->d_work.cap < work_bytes) {
         std::vector<unsigned char> z(work_bytes, 0);
         if (!c->d_work.upload(z.data(), work_bytes, st)) { set_error("hjr_render: work buffer allocation failed"); return HJR_ERR_DEVICE; }
@@ -270,16 +274,12 @@ static int render_impl(hjr_ctx* c, const hjr_params* p, void* d_color, void* d_a
     kp.cam_f = p->camera.f;
 
     const bool stats = (p->flags & HJR_FLAG_STATS) != 0;
-    kp.n_node_f4 = c->frame.n_nodes * HJR_NODE_F4;
+    kp.n_node_f4 = c->frame.n_nodes * (c->frame.width == 2 ? HJR_NODE2_F4 : HJR_NODE4_F4);
     kp.n_tri_f4 = (c->frame.n_tris ? c->frame.n_tris : 1u) * HJR_TRI_F4;
     kp.stack_depth = c->frame.stack_need; // exact worst case for this tree (host/frame.cpp)
-    // stage the whole BVH in LDS when it fits beside the traversal stacks of one HJR_BLOCK_LDS-thread workgroup
-    // (HJR_LDS_BVH=0 disables); 16-bit stack entries (node ids < 32768, leaf-order triangle ids < 8192) when 32-bit ones do not fit
-    const size_t bvh_bytes = ((size_t)kp.n_node_f4 + kp.n_tri_f4) * 16;
-    int lds_mode = 0;
-    if ((size_t)HJR_BLOCK_LDS * kp.stack_depth * 4 + 16 + bvh_bytes <= HJR_LDS_BUDGET - 1024) lds_mode = 1;
-    else if ((size_t)HJR_BLOCK_LDS * kp.stack_depth * 2 + 16 + bvh_bytes <= HJR_LDS_BUDGET - 1024 && c->frame.n_nodes < 32768u && c->frame.n_tris < 8192u) lds_mode = 2;
-    if (const char* e = getenv("HJR_LDS_BVH")) { if (atoi(e) == 0) lds_mode = 0; }
+    // node format / LDS staging were decided by the host builder for this frame (host/frame.cpp)
+    int lds_mode = c->frame.lds_mode;
+    if (lds_mode == 0 && c->frame.width == 2) lds_mode = 3;
     HIPCHK(hipEventRecord(c->ev0, st));
     int lrc = 0;
     switch (p->integrator * 2 + (stats ? 1 : 0)) {
@@ -312,11 +312,12 @@ static int fetch_stats(hjr_ctx* c, hipStream_t st)
     for (int i = 0; i < HJR_NSTAT; i++) dst[i] = h[i];
 #ifdef HJR_TIMING
     {
-        unsigned long long tk[6];
+        unsigned long long tk[8];
         HIPCHK(hipMemcpy(tk, (char*)c->d_work.p + 16 + HJR_NSTAT * 8, sizeof(tk), hipMemcpyDeviceToHost));
         double tot = 0; for (int i = 0; i < 6; i++) tot += (double)tk[i];
         fprintf(stderr, "[hjr timing] rr/regen %.1f%%  trace %.1f%%  resolve+hit %.1f%%  nee(light+eval) %.1f%%  bsdf sample %.1f%%  rest %.1f%%  (total %.3g wave-clocks)\n",
                 100 * tk[0] / tot, 100 * tk[1] / tot, 100 * tk[2] / tot, 100 * tk[3] / tot, 100 * tk[4] / tot, 100 * tk[5] / tot, tot);
+        fprintf(stderr, "[hjr timing]   inside trace: inner-node loop %.1f%%  leaf/triangles+switch %.1f%% (of total)\n", 100 * tk[6] / tot, 100 * tk[7] / tot);
     }
 #endif
     return HJR_OK;

@@ -464,7 +464,12 @@ HD float bsdf_pdf(const Surface& s, f3 wo, f3 wi)
 }
 
 // ------------------------------------------------------------------ traversal: replaces optixTrace (kernel/rt.h:15-69) + RT cores
-struct Counters { uint32_t box, tri; };
+struct Counters {
+    uint32_t box, tri;
+#ifdef HJR_TIMING
+    unsigned long long t_node, t_leaf;
+#endif
+};
 
 HD float dotf(f3 a, f3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
 HD f3 crossf(f3 a, f3 b)
@@ -512,9 +517,7 @@ HD uint32_t stack_dec(uint16_t r16)
 // 1e-30 are clamped (sign kept) so that inv stays finite and no inf - inf can appear for axis-parallel rays.
 struct BoxRay {
     f3 inv, oi;
-#if HJR_BVH_WIDTH == 4
-    uint32_t sx, sy, sz; // 1 when the direction component is negative: near plane row = hi
-#endif
+    uint32_t sx, sy, sz; // BVH4 only: 1 when the direction component is negative (near plane row = hi)
 };
 HD float box_dir(float d) { return (fabsf(d) < 1e-30f) ? copysignf(1e-30f, d) : d; }
 HD BoxRay box_ray(f3 o, f3 d)
@@ -523,20 +526,18 @@ HD BoxRay box_ray(f3 o, f3 d)
     const f3 dd = V(box_dir(d.x), box_dir(d.y), box_dir(d.z));
     r.inv = V(__builtin_amdgcn_rcpf(dd.x), __builtin_amdgcn_rcpf(dd.y), __builtin_amdgcn_rcpf(dd.z));
     r.oi = V(-o.x * r.inv.x, -o.y * r.inv.y, -o.z * r.inv.z);
-#if HJR_BVH_WIDTH == 4
-    r.sx = dd.x < 0.0f ? 1u : 0u; r.sy = dd.y < 0.0f ? 1u : 0u; r.sz = dd.z < 0.0f ? 1u : 0u;
-#endif
+    r.sx = dd.x < 0.0f ? 1u : 0u; r.sy = dd.y < 0.0f ? 1u : 0u; r.sz = dd.z < 0.0f ? 1u : 0u; // dead code in the BVH2 kernels
     return r;
 }
 
 #define HJR_TRAV_DONE 0xffffffffu
 // One inner-node step: tests the children of node `cur` against [tmin, tfar], continues with the nearest hit child, pushes
 // the other hit children, or pops (HJR_TRAV_DONE when the stack is empty).  Returns the number of boxes tested.
-template <int BLOCK, typename ST>
+template <int WIDTH, int BLOCK, typename ST>
 HD uint32_t node_step(const float4* nodes, uint32_t& cur, const BoxRay& R, float tmin, float tfar, ST* stack, int& sp)
 {
-    const float4* nd = nodes + cur * HJR_NODE_F4;
-#if HJR_BVH_WIDTH == 2
+    if constexpr (WIDTH == 2) {
+    const float4* nd = nodes + cur * HJR_NODE2_F4;
     const float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
     const f3 inv = R.inv, oi = R.oi;
     float t0 = fmaf(q0.x, inv.x, oi.x), t1 = fmaf(q0.w, inv.x, oi.x);
@@ -565,7 +566,8 @@ HD uint32_t node_step(const float4* nodes, uint32_t& cur, const BoxRay& R, float
     else if (sp > 0) { sp--; cur = stack_dec(stack[sp * BLOCK]); }
     else cur = HJR_TRAV_DONE;
     return 2u;
-#else
+    } else {
+    const float4* nd = nodes + cur * HJR_NODE4_F4;
     // near / far plane rows picked by the ray's direction signs: no min/max per axis
     const float4 nx = nd[0 + R.sx], fx = nd[1 - R.sx];
     const float4 ny = nd[2 + R.sy], fy = nd[3 - R.sy];
@@ -592,13 +594,13 @@ HD uint32_t node_step(const float4* nodes, uint32_t& cur, const BoxRay& R, float
     else if (sp > 0) { sp--; cur = stack_dec(stack[sp * BLOCK]); }
     else cur = HJR_TRAV_DONE;
     return 4u;
-#endif
+    }
 }
 
 struct Hit { float t, b1, b2; uint32_t k, prim; };
 
 // stack: this lane's column of the LDS stack, element i at stack[i * BLOCK]
-template <bool ANY, bool STATS, int BLOCK, typename ST>
+template <bool ANY, bool STATS, int WIDTH, int BLOCK, typename ST>
 HD bool traverse(const float4* nodes, const float4* tris, f3 o, f3 d, float tmin, float tmax, Hit& hit, ST* stack, Counters& cnt)
 {
     const BoxRay R = box_ray(o, d);
@@ -608,7 +610,7 @@ HD bool traverse(const float4* nodes, const float4* tris, f3 o, f3 d, float tmin
     hit.t = tmax;
     for (;;) {
         while (!(cur & HJR_LEAF_FLAG)) { // descend through inner nodes until this lane holds a leaf (or is done)
-            const uint32_t nb = node_step<BLOCK, ST>(nodes, cur, R, tmin, hit.t, stack, sp);
+            const uint32_t nb = node_step<WIDTH, BLOCK, ST>(nodes, cur, R, tmin, hit.t, stack, sp);
             if (STATS) cnt.box += nb;
         }
         if (cur == HJR_TRAV_DONE) break;
@@ -639,7 +641,7 @@ HD bool traverse(const float4* nodes, const float4* tris, f3 o, f3 d, float tmin
 // resolved, without waiting for the rest of the wave, so the wave's trip count is max_lanes(tripsA + tripsB) instead of
 // max(tripsA) + max(tripsB) — the SIMT cost of per-lane trip-count variance drops by ~1/3 (profiles/r01_experiments.md).
 // Results are identical to two separate traversals.
-template <bool STATS, int BLOCK, typename ST>
+template <bool STATS, int WIDTH, int BLOCK, typename ST>
 HD void traverse_fused(const float4* nodes, const float4* tris, const bool a_valid, const f3 ao, const f3 ad, const float a_tmax, const bool b_valid,
                        const f3 bo, const f3 bd, bool& occluded, Hit& hit, ST* stack, Counters& ca, Counters& cb)
 {
@@ -653,13 +655,19 @@ HD void traverse_fused(const float4* nodes, const float4* tris, const bool a_val
     BoxRay R = box_ray(o, d);
     int sp = 0;
     uint32_t cur = (phase < 2) ? 0u : HJR_TRAV_DONE;
+#ifdef HJR_TIMING
+    unsigned long long t_node = 0, t_leaf = 0, t_last = __builtin_amdgcn_s_memtime();
+#endif
     while (phase < 2) {
         // "while-while" traversal: every lane first descends through inner nodes until it holds a leaf (or is out of work) ...
         while (!(cur & HJR_LEAF_FLAG)) {
             const float tfar = (phase == 0) ? a_tmax : hit.t;
-            const uint32_t nb = node_step<BLOCK, ST>(nodes, cur, R, tmin, tfar, stack, sp);
+            const uint32_t nb = node_step<WIDTH, BLOCK, ST>(nodes, cur, R, tmin, tfar, stack, sp);
             if (STATS) { if (phase == 0) ca.box += nb; else cb.box += nb; }
         }
+#ifdef HJR_TIMING
+        { __builtin_amdgcn_sched_barrier(0); unsigned long long now_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); t_node += now_ - t_last; t_last = now_; }
+#endif
         // ... then all lanes test their leaf's triangles together
         bool done = (cur == HJR_TRAV_DONE);
         if (!done) {
@@ -692,7 +700,13 @@ HD void traverse_fused(const float4* nodes, const float4* tris, const bool a_val
                 sp = 0; cur = 0;
             } else { phase = 2; cur = HJR_TRAV_DONE; }
         }
+#ifdef HJR_TIMING
+        { __builtin_amdgcn_sched_barrier(0); unsigned long long now_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); t_leaf += now_ - t_last; t_last = now_; }
+#endif
     }
+#ifdef HJR_TIMING
+    ca.t_node = t_node; ca.t_leaf = t_leaf;
+#endif
 }
 
 // ------------------------------------------------------------------ closest-hit / miss programs (build-defined)
@@ -741,12 +755,12 @@ HD void hit_program(const KParams& P, const float4* tris, const Hit& h, HitInfo&
 }
 
 // RayTrace (rt.h:43-69): stand-alone closest-hit query (used by MIS' BSDF-sampled light ray)
-template <bool STATS, int BLOCK, typename ST>
+template <bool STATS, int WIDTH, int BLOCK, typename ST>
 HD void ray_trace(const KParams& P, const float4* nodes, const float4* tris, f3 o, f3 d, HitInfo& prd, ST* stack, unsigned long long* lc)
 {
     Hit h;
     Counters c; c.box = 0; c.tri = 0;
-    traverse<false, STATS, BLOCK, ST>(nodes, tris, o, d, 0.001f, 1e16f, h, stack, c);
+    traverse<false, STATS, WIDTH, BLOCK, ST>(nodes, tris, o, d, 0.001f, 1e16f, h, stack, c);
     if (STATS) { lc[1] += 1; lc[3] += c.box; lc[4] += c.tri; }
     hit_program<STATS>(P, tris, h, prd, lc);
 }
@@ -813,7 +827,7 @@ HD void start_path(const KParams& P, PathState& ps, uint32_t px, uint32_t py, ui
 // workgroup of BLOCK threads per CU shares the copy.  Chosen by the host when the scene fits (hjr_device.hip).
 extern __shared__ float4 hjr_smem[];
 
-template <int INTEGRATOR, bool STATS, int BLOCK, bool LDSBVH, bool STACK16>
+template <int INTEGRATOR, bool STATS, int BLOCK, bool LDSBVH, bool STACK16, int WIDTH>
 __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_render_kernel(const KParams P)
 {
     typedef typename std::conditional<STACK16, uint16_t, uint32_t>::type ST; // stack entry type
@@ -849,9 +863,9 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
     const float inv_spp = 1.0f / (float)P.spp;
 #ifdef HJR_TIMING
     // diagnostic build: wave-clock shares of the loop's phases, summed per wave into P.stats[10..15] (never in the shipped build)
-    unsigned long long tk[6] = { 0, 0, 0, 0, 0, 0 };
+    unsigned long long tk[6] = { 0, 0, 0, 0, 0, 0 }, tk6 = 0, tk7 = 0;
     unsigned long long tstamp = __builtin_amdgcn_s_memtime();
-#define HJR_TICK(i) { unsigned long long now_ = __builtin_amdgcn_s_memtime(); tk[i] += now_ - tstamp; tstamp = now_; }
+#define HJR_TICK(i) { __builtin_amdgcn_sched_barrier(0); unsigned long long now_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); tk[i] += now_ - tstamp; tstamp = now_; }
 #else
 #define HJR_TICK(i)
 #endif
@@ -938,7 +952,10 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
         Hit h;
         {
             Counters ca, cb; ca.box = ca.tri = cb.box = cb.tri = 0;
-            traverse_fused<STATS, BLOCK, ST>(nodes, tris, sh_valid, sh_o, sh_d, sh_tmax, tracing, ps.ro, ps.rd, occluded, h, stack, ca, cb);
+            traverse_fused<STATS, WIDTH, BLOCK, ST>(nodes, tris, sh_valid, sh_o, sh_d, sh_tmax, tracing, ps.ro, ps.rd, occluded, h, stack, ca, cb);
+#ifdef HJR_TIMING
+            tk6 += ca.t_node; tk7 += ca.t_leaf;
+#endif
             if (STATS) {
                 if (sh_valid) { lc[2] += 1; lc[5] += ca.box; lc[6] += ca.tri; }
                 if (tracing) { lc[1] += 1; lc[3] += cb.box; lc[4] += cb.tri; }
@@ -1016,7 +1033,7 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
                     if (sh_valid) {
                         Hit shh;
                         Counters c; c.box = 0; c.tri = 0;
-                        const bool occ = traverse<true, STATS, BLOCK, ST>(nodes, tris, sh_o, sh_d, 0.001f, sh_tmax, shh, stack, c);
+                        const bool occ = traverse<true, STATS, WIDTH, BLOCK, ST>(nodes, tris, sh_o, sh_d, 0.001f, sh_tmax, shh, stack, c);
                         if (STATS) { lc[2] += 1; lc[5] += c.box; lc[6] += c.tri; }
                         if (!occ) ps.L = ps.L + sh_contrib;
                         sh_valid = false;
@@ -1027,7 +1044,7 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
                     const f3 wi = local_to_world(local_wi, t, n, b);
                     const float cosine1 = absdot(wi, n);
                     HitInfo lh;
-                    ray_trace<STATS, BLOCK, ST>(P, nodes, tris, prd.position, wi, lh, stack, lc);
+                    ray_trace<STATS, WIDTH, BLOCK, ST>(P, nodes, tris, prd.position, wi, lh, stack, lc);
                     if (lh.is_hit) {
                         if (lh.is_light) {
                             const float cosine2 = absdot(-wi, lh.normal);
@@ -1078,7 +1095,7 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
         HJR_TICK(5)
     }
 #ifdef HJR_TIMING
-    if (lane == 0) for (int i = 0; i < 6; i++) atomicAdd(&P.stats[HJR_NSTAT + i], tk[i]);
+    if (lane == 0) { for (int i = 0; i < 6; i++) atomicAdd(&P.stats[HJR_NSTAT + i], tk[i]); atomicAdd(&P.stats[HJR_NSTAT + 6], tk6); atomicAdd(&P.stats[HJR_NSTAT + 7], tk7); }
 #endif
 
     if (STATS) {

@@ -10,22 +10,24 @@
 #define HJR_LEAF_DEFAULT 2u          /* builder default: measured fastest on MI355X (profiles/r01_experiments.md) */
 #define HJR_MAX_TRIS (1u << 27)
 
-#ifndef HJR_BVH_WIDTH
-#define HJR_BVH_WIDTH 2 /* measured on MI355X: the 2-wide tree is faster than the collapsed 4-wide one once the BVH sits in LDS (profiles/r01_experiments.md) */
-#endif
-#if HJR_BVH_WIDTH == 2
-/* BVH2 node, 64 B = 4 x float4; holds the (padded) boxes of both children.
+/* Two node formats; the host picks per frame (host/frame.cpp):
+ *  - BVH2 when the whole tree + triangles fit into LDS beside the traversal stacks (small scenes): fewest VALU
+ *    instructions per ray, and LDS hides the extra dependent steps;
+ *  - BVH4 (the BVH2 collapsed) otherwise: half the dependent memory round trips when nodes come from L2 / HBM.
+ * Measured on MI355X (profiles/r01_experiments.md): cornelbox in LDS 223 ms (BVH2) vs 249 ms (BVH4); 1 M-triangle stress scene
+ * from memory 643 ms (BVH2) vs 501 ms (BVH4).
+ *
+ * BVH2 node, 64 B = 4 x float4; holds the (padded) boxes of both children.
  *   q0 = (lo0.x lo0.y lo0.z hi0.x)  q1 = (hi0.y hi0.z lo1.x lo1.y)  q2 = (lo1.z hi1.x hi1.y hi1.z)
- *   q3 = (child0, child1, 0, 0) as uint bits */
-#define HJR_NODE_F4 4
-#else
-/* BVH4 node (binned-SAH BVH2 collapsed: largest-area inner child expanded first), 112 B = 7 x float4, child-major planes so
- * that one 16-byte read yields the same plane of all four children:
+ *   q3 = (child0, child1, 0, 0) as uint bits
+ * BVH4 node, 112 B = 7 x float4, child-major planes so that one 16-byte read yields the same plane of all four children:
  *   q0 = lo.x[0..3]  q1 = hi.x[0..3]  q2 = lo.y[0..3]  q3 = hi.y[0..3]  q4 = lo.z[0..3]  q5 = hi.z[0..3]  q6 = child refs[0..3]
- * A ray picks its near/far plane rows by the sign of its direction (byte offset 0 or 16), so the slab test needs no min/max.
- * Unused child slots: inverted box (+1e30 / -1e30) and an empty-leaf ref. */
-#define HJR_NODE_F4 7
-#endif
+ *   A ray picks its near/far plane rows by the sign of its direction, so the slab test needs no min/max.
+ *   Unused child slots: inverted box (+1e30 / -1e30) and an empty-leaf ref. */
+#define HJR_NODE2_F4 4
+#define HJR_NODE4_F4 7
+#define HJR_BLOCK_LDS 1024          /* threads of the one-per-CU workgroup that shares an LDS copy of the BVH (16 waves = 4 per SIMD) */
+#define HJR_LDS_BUDGET (159u * 1024u)
 /* Triangle (leaf order), 48 B = 3 x float4: world-space vertices + global prim id.
  *   g0 = (v0.x v0.y v0.z v1.x)  g1 = (v1.y v1.z v2.x v2.y)  g2 = (v2.z, prim_id bits, 0, 0) */
 #define HJR_TRI_F4 3

@@ -159,7 +159,7 @@ struct Builder {
 
 } // namespace
 
-bool build_frame(const SceneCopy& sc, const float* M, const float* Mi, uint32_t n_inst, FrameData& out, std::string& err)
+bool build_frame(const SceneCopy& sc, const float* M, const float* Mi, uint32_t n_inst, bool allow_lds, FrameData& out, std::string& err)
 {
     if (n_inst != sc.n_instances) { err = "instance count does not match the uploaded scene"; return false; }
     const uint32_t n = sc.n_triangles;
@@ -245,16 +245,13 @@ bool build_frame(const SceneCopy& sc, const float* M, const float* Mi, uint32_t 
 
     out.tri_geom.assign((size_t)std::max(n, 1u) * HJR_TRI_F4 * 4, 0.0f);
     auto leaf_ref = [](uint32_t first, uint32_t count) { return HJR_LEAF_FLAG | (count << 27) | first; };
-    if (n == 0) {
-        out.nodes.assign((size_t)HJR_NODE_F4 * 4, 0.0f);
-#if HJR_BVH_WIDTH == 2
-        out.nodes[12] = u2f(leaf_ref(0, 0)); out.nodes[13] = u2f(leaf_ref(0, 0));
-#else
+    if (n == 0) { // empty scene: one BVH4 root with four empty slots
+        out.width = 4; out.lds_mode = 0;
+        out.nodes.assign((size_t)HJR_NODE4_F4 * 4, 0.0f);
         for (int c = 0; c < 4; c++) {
             for (int a = 0; a < 3; a++) { out.nodes[8 * a + c] = 1e30f; out.nodes[8 * a + 4 + c] = -1e30f; }
             out.nodes[24 + c] = u2f(leaf_ref(0, 0));
         }
-#endif
         out.n_nodes = 1;
         out.stack_need = 2;
         return true;
@@ -269,7 +266,24 @@ bool build_frame(const SceneCopy& sc, const float* M, const float* Mi, uint32_t 
         memcpy(g, &wv[9 * (size_t)t], 9 * sizeof(float));
         g[9] = u2f(t);
     }
-#if HJR_BVH_WIDTH == 2
+    // node format: BVH2 if tree + triangles + stacks fit into the LDS of one HJR_BLOCK_LDS-thread workgroup, else BVH4
+    uint32_t n_inner2 = 0;
+    for (size_t i = 0; i < B.nodes.size(); i++) if (B.nodes[i].left >= 0) n_inner2++;
+    if (n_inner2 == 0) n_inner2 = 1;
+    const size_t bvh2_bytes = (size_t)n_inner2 * HJR_NODE2_F4 * 16 + (size_t)n * HJR_TRI_F4 * 16;
+    const size_t stack2 = (size_t)B.max_depth + 2;
+    int lds_mode = 0;
+    if (allow_lds) {
+        if ((size_t)HJR_BLOCK_LDS * stack2 * 4 + 16 + bvh2_bytes <= HJR_LDS_BUDGET) lds_mode = 1;
+        else if ((size_t)HJR_BLOCK_LDS * stack2 * 2 + 16 + bvh2_bytes <= HJR_LDS_BUDGET && n_inner2 < 32768u && n < 8192u) lds_mode = 2;
+    }
+    if (const char* e = getenv("HJR_BVH_WIDTH")) { // tuning knob: force a node format (forcing 4 also forces the memory path)
+        int v = atoi(e);
+        if (v == 4) lds_mode = 0;
+        out.width = (v == 2 || (v != 4 && lds_mode)) ? 2u : 4u;
+    } else out.width = lds_mode ? 2u : 4u;
+    out.lds_mode = lds_mode;
+    if (out.width == 2) {
     // emit inner nodes depth-first; a root that is itself a leaf (n == 1) gets an empty sibling
     std::vector<int> inner_id(B.nodes.size(), -1);
     uint32_t n_inner = 0;
@@ -283,8 +297,7 @@ bool build_frame(const SceneCopy& sc, const float* M, const float* Mi, uint32_t 
         q[12] = u2f(leaf_ref(r.first, r.count)); q[13] = u2f(leaf_ref(0, 0));
         out.n_nodes = 1;
         out.stack_need = 2;
-        return true;
-    }
+    } else {
     out.nodes.assign((size_t)n_inner * 16, 0.0f);
     out.n_nodes = n_inner;
     out.stack_need = B.max_depth + 2;
@@ -299,7 +312,8 @@ bool build_frame(const SceneCopy& sc, const float* M, const float* Mi, uint32_t 
             q[12 + c] = u2f(ref);
         }
     }
-#else
+    }
+    } else {
     // collapse the BVH2 into a BVH4: a wide node starts from the two children of a BVH2 inner node and repeatedly replaces its
     // largest-area inner child by that child's two children until it has four children (or only leaves)
     struct Wide { int child[4]; int n; };
@@ -332,9 +346,9 @@ bool build_frame(const SceneCopy& sc, const float* M, const float* Mi, uint32_t 
         }
     }
     out.n_nodes = (uint32_t)wide.size();
-    out.nodes.assign(wide.size() * (size_t)HJR_NODE_F4 * 4, 0.0f);
+    out.nodes.assign(wide.size() * (size_t)HJR_NODE4_F4 * 4, 0.0f);
     for (size_t i = 0; i < wide.size(); i++) {
-        float* q = &out.nodes[i * (size_t)HJR_NODE_F4 * 4];
+        float* q = &out.nodes[i * (size_t)HJR_NODE4_F4 * 4];
         for (int c = 0; c < 4; c++) {
             if (c < wide[i].n) {
                 const BuildNode& ch = B.nodes[(size_t)wide[i].child[c]];
@@ -361,7 +375,7 @@ bool build_frame(const SceneCopy& sc, const float* M, const float* Mi, uint32_t 
         }
         out.stack_need = worst + 1;
     }
-#endif
+    }
     return true;
 }
 

@@ -13,13 +13,15 @@
 namespace hjr {
 
 struct FrameData {
-    std::vector<float> nodes;      // HJR_NODE_F4 float4 per inner node
+    std::vector<float> nodes;      // HJR_NODE2_F4 / HJR_NODE4_F4 float4 per inner node
     std::vector<float> tri_geom;   // HJR_TRI_F4 float4 per triangle, leaf order
     std::vector<float> tri_shade;  // HJR_SHADE_F4 float4 per triangle, global prim order
     std::vector<uint32_t> tri_inst;// instance id per global prim
     std::vector<float> lights;     // HJR_LIGHT_F4 float4 per emissive triangle
     uint32_t n_tris = 0, n_nodes = 0, n_lights = 0, depth = 0;
     uint32_t stack_need = 2; // worst-case traversal stack entries per lane for this tree
+    uint32_t width = 2;      // 2 or 4 (node format, hjr_layout.h)
+    int lds_mode = 0;        // 0: nodes/triangles read from memory; 1: staged in LDS, 32-bit stack entries; 2: 16-bit entries
 };
 
 // Owning copy of an hjr_scene_view (cpySceneDataToDevice keeps the host vectors alive too, renderer.h:197-255).
@@ -31,7 +33,8 @@ struct SceneCopy {
     bool set(const hjr_scene_view& v, std::string& err);
 };
 
-bool build_frame(const SceneCopy& sc, const float* transforms12, const float* inv12, uint32_t n_instances,
+// allow_lds: let small scenes use the LDS-resident BVH2 layout
+bool build_frame(const SceneCopy& sc, const float* transforms12, const float* inv12, uint32_t n_instances, bool allow_lds,
                  FrameData& out, std::string& err);
 
 } // namespace hjr

@@ -168,16 +168,21 @@ extern "C" int hjr_set_lut(hjr_ctx* c, const uint8_t* rgba, int w, int h)
 // number of wavefront-sized batches of work; HJR_BLOCKS_PER_CU overrides the occupancy query
 template <int I, bool S, int W> static int launch_mem(const hjr_ctx* c, const KParams& kp, uint64_t n_items, hipStream_t st);
 // lds_mode: 0 = BVH4 read from memory, 1 = BVH2 staged in LDS with 32-bit stack entries, 2 = with 16-bit entries, 3 = BVH2 from memory
-template <int I, bool S, bool S16> static int launch_lds(const hjr_ctx* c, const KParams& kp, uint64_t n_items, hipStream_t st)
+template <int I, bool S, bool S16, bool A> static int launch_lds2(const hjr_ctx* c, const KParams& kp, uint64_t n_items, hipStream_t st)
 {
     const size_t smem = (((size_t)HJR_BLOCK_LDS * kp.stack_depth * (S16 ? 2 : 4) + 15) / 16) * 16 + ((size_t)kp.n_node_f4 + kp.n_tri_f4) * 16;
-    auto kern = hjr_render_kernel<I, S, HJR_BLOCK_LDS, true, S16, 2>;
+    auto kern = hjr_render_kernel<I, S, HJR_BLOCK_LDS, true, S16, 2, A>;
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return -1;
     uint64_t blocks = (uint64_t)c->n_cus;
     uint64_t max_useful = (n_items + HJR_BLOCK_LDS - 1) / HJR_BLOCK_LDS;
     if (blocks > max_useful) blocks = max_useful ? max_useful : 1;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(HJR_BLOCK_LDS), smem, st, kp);
     return 0;
+}
+// the albedo / normal AOV sums cost 6 VGPRs per lane: a separate instantiation for callers that only want aov_color
+template <int I, bool S, bool S16> static int launch_lds(const hjr_ctx* c, const KParams& kp, uint64_t n_items, hipStream_t st)
+{
+    return (kp.aov_albedo || kp.aov_normal) ? launch_lds2<I, S, S16, true>(c, kp, n_items, st) : launch_lds2<I, S, S16, false>(c, kp, n_items, st);
 }
 template <int I, bool S> static int launch(const hjr_ctx* c, const KParams& kp, uint64_t n_items, int lds_mode, hipStream_t st)
 {
@@ -189,7 +194,7 @@ template <int I, bool S> static int launch(const hjr_ctx* c, const KParams& kp, 
 template <int I, bool S, int W> static int launch_mem(const hjr_ctx* c, const KParams& kp, uint64_t n_items, hipStream_t st)
 {
     const size_t smem = (size_t)HJR_BLOCK * kp.stack_depth * 4;
-    auto kern = hjr_render_kernel<I, S, HJR_BLOCK, false, false, W>;
+    auto kern = hjr_render_kernel<I, S, HJR_BLOCK, false, false, W, true>;
     int per_cu = 0;
     if (c->blocks_per_cu > 0) per_cu = c->blocks_per_cu;
     else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, HJR_BLOCK, smem) != hipSuccess || per_cu < 1)

@@ -827,7 +827,7 @@ HD void start_path(const KParams& P, PathState& ps, uint32_t px, uint32_t py, ui
 // workgroup of BLOCK threads per CU shares the copy.  Chosen by the host when the scene fits (hjr_device.hip).
 extern __shared__ float4 hjr_smem[];
 
-template <int INTEGRATOR, bool STATS, int BLOCK, bool LDSBVH, bool STACK16, int WIDTH>
+template <int INTEGRATOR, bool STATS, int BLOCK, bool LDSBVH, bool STACK16, int WIDTH, bool AOVS>
 __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_render_kernel(const KParams P)
 {
     typedef typename std::conditional<STACK16, uint16_t, uint32_t>::type ST; // stack entry type
@@ -922,13 +922,13 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
             const size_t pix = (size_t)px + (size_t)py * P.width;
             if (P.n_chunks == 1u) { // the item is the whole pixel: mean = chunk sum * (1 / spp)
                 P.aov_color[pix] = make_float4(sumL.x * inv_spp, sumL.y * inv_spp, sumL.z * inv_spp, 1.0f);
-                if (P.aov_albedo) P.aov_albedo[pix] = make_float4(sumA.x * inv_spp, sumA.y * inv_spp, sumA.z * inv_spp, 1.0f);
-                if (P.aov_normal) P.aov_normal[pix] = make_float4(sumN.x * inv_spp, sumN.y * inv_spp, sumN.z * inv_spp, 1.0f);
+                if (AOVS && P.aov_albedo) P.aov_albedo[pix] = make_float4(sumA.x * inv_spp, sumA.y * inv_spp, sumA.z * inv_spp, 1.0f);
+                if (AOVS && P.aov_normal) P.aov_normal[pix] = make_float4(sumN.x * inv_spp, sumN.y * inv_spp, sumN.z * inv_spp, 1.0f);
             } else { // chunk sum -> HBM; hjr_finalize_kernel adds the chunks of a pixel in chunk order
                 const size_t slot = (size_t)chunk * ((size_t)P.width * P.height) + pix;
                 P.part_color[slot] = make_float4(sumL.x, sumL.y, sumL.z, 0.0f);
-                if (P.part_albedo) P.part_albedo[slot] = make_float4(sumA.x, sumA.y, sumA.z, 0.0f);
-                if (P.part_normal) P.part_normal[slot] = make_float4(sumN.x, sumN.y, sumN.z, 0.0f);
+                if (AOVS && P.part_albedo) P.part_albedo[slot] = make_float4(sumA.x, sumA.y, sumA.z, 0.0f);
+                if (AOVS && P.part_normal) P.part_normal[slot] = make_float4(sumN.x, sumN.y, sumN.z, 0.0f);
             }
             write_pending = false;
         };
@@ -978,7 +978,7 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
         if (tracing) {
             HitInfo prd;
             hit_program<STATS>(P, tris, h, prd, lc);
-            if (ps.depth == 0) { sumA = sumA + prd.surf.basecolor; sumN = sumN + prd.normal; } // rt.h:191-194
+            if (AOVS && ps.depth == 0) { sumA = sumA + prd.surf.basecolor; sumN = sumN + prd.normal; } // rt.h:191-194
             if (!prd.is_hit || prd.is_light) {
                 // NEE / MIS count emission only at depth 0 (rt.h:196-208, 318-330); Pathtrace always (rt.h:118-126)
                 if (INTEGRATOR == HJR_INTEGRATOR_PT_ || ps.depth == 0) ps.L = ps.L + ps.thr * prd.emission;

@@ -792,19 +792,28 @@ HD f3 light_sample(const KParams& P, CMJState& st, float& pdf, f3& normal, f3& e
 
 struct PathState {
     f3 ro, rd, thr, L;
-    CMJState st;
+    uint32_t rng_depth; // CMJState.depth; the other CMJState fields are functions of (frame, spp, s, seed, pixel): rebuilt on use
     int depth;
 };
+
+// CMJState of the path that is running sample s of pixel (px, py) (build-defined seeding)
+HD CMJState path_rng(const KParams& P, uint32_t px, uint32_t py, uint32_t s, uint32_t depth)
+{
+    CMJState st;
+    st.n_spp = (unsigned long long)P.frame * (unsigned long long)P.spp + (unsigned long long)s;
+    st.scramble = P.seed;
+    st.depth = depth;
+    st.image_idx = px + py * P.width;
+    return st;
+}
 
 // __raygen__rg for one sample (build-defined; SURVEY §8a a1/a2, stale ptx:33-106): CMJ stream keyed by
 // (frame * spp + s, seed, pixel), first 2-D draw = sub-pixel jitter, u = (2(x+jx) - W) / H, v = (2(y+jy) - H) / H
 HD void start_path(const KParams& P, PathState& ps, uint32_t px, uint32_t py, uint32_t s)
 {
-    ps.st.n_spp = (unsigned long long)P.frame * (unsigned long long)P.spp + (unsigned long long)s;
-    ps.st.scramble = P.seed;
-    ps.st.depth = 0;
-    ps.st.image_idx = px + py * P.width;
-    f2 j = cmj_2d(ps.st);
+    CMJState st = path_rng(P, px, py, s, 0u);
+    f2 j = cmj_2d(st);
+    ps.rng_depth = st.depth;
     float W = (float)P.width, H = (float)P.height;
     float u = (2.0f * ((float)px + j.x) - W) / H;
     float v = (2.0f * ((float)py + j.y) - H) / H;
@@ -859,7 +868,7 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
     PathState ps;
     ps.ro = ps.rd = ps.thr = ps.L = V1(0.0f);
     ps.depth = 0;
-    ps.st.n_spp = 0; ps.st.scramble = 0; ps.st.depth = 0; ps.st.image_idx = 0;
+    ps.rng_depth = 0;
     const float inv_spp = 1.0f / (float)P.spp;
 #ifdef HJR_TIMING
     // diagnostic build: wave-clock shares of the loop's phases, summed per wave into P.stats[10..15] (never in the shipped build)
@@ -940,7 +949,10 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
         while (has_item) {
             if (!path_live) { start_path(P, ps, px, py, s); path_live = true; }
             const float russian_p = fmaxf(ps.thr.x, fmaxf(ps.thr.y, ps.thr.z));
-            if (russian_p < cmj_1d(ps.st)) { fin_pending = true; fin_L = ps.L; close_sample(); continue; }
+            CMJState rr = path_rng(P, px, py, s, ps.rng_depth);
+            const float xi_rr = cmj_1d(rr);
+            ps.rng_depth = rr.depth;
+            if (russian_p < xi_rr) { fin_pending = true; fin_L = ps.L; close_sample(); continue; }
             ps.thr = ps.thr / russian_p;
             tracing = true;
             break;
@@ -987,6 +999,7 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
                 if (write_pending) write_out();
             } else {
                 HJR_TICK(2)
+                CMJState st = path_rng(P, px, py, s, ps.rng_depth);
                 const Surface& sf = prd.surf;
                 f3 t, b;
                 const f3 n = prd.normal;
@@ -996,7 +1009,7 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
                 if (INTEGRATOR != HJR_INTEGRATOR_PT_ && P.n_lights >= 1u) { // light_prim_count < 1: no contribution (UB in the reference)
                     float light_pdf;
                     f3 light_color, light_normal;
-                    const f3 light_position = light_sample(P, ps.st, light_pdf, light_normal, light_color);
+                    const f3 light_position = light_sample(P, st, light_pdf, light_normal, light_color);
                     if (STATS) lc[8] += 1;
                     const f3 so = prd.position;
                     f3 sd;
@@ -1040,7 +1053,7 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
                     }
                     float pt_pdf = 1.0f; // uninitialised in the reference when msGGX returns early; defined as 1
                     f3 local_wi = V(0.0f, 1.0f, 0.0f);
-                    const f3 brdf = bsdf_sample(P, sf, local_wo, local_wi, pt_pdf, ps.st);
+                    const f3 brdf = bsdf_sample(P, sf, local_wo, local_wi, pt_pdf, st);
                     const f3 wi = local_to_world(local_wi, t, n, b);
                     const float cosine1 = absdot(wi, n);
                     HitInfo lh;
@@ -1078,12 +1091,13 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
                 HJR_TICK(3)
                 float pdf = 1.0f;
                 f3 local_wi = V(0.0f, 1.0f, 0.0f);
-                if (INTEGRATOR != HJR_INTEGRATOR_PT_) (void)cmj_2d(ps.st); // drawn and discarded by the reference (rt.h:266, 426)
-                const f3 bsdf = bsdf_sample(P, sf, local_wo, local_wi, pdf, ps.st);
+                if (INTEGRATOR != HJR_INTEGRATOR_PT_) (void)cmj_2d(st); // drawn and discarded by the reference (rt.h:266, 426)
+                const f3 bsdf = bsdf_sample(P, sf, local_wo, local_wi, pdf, st);
                 const f3 wi = local_to_world(local_wi, t, n, b);
                 ps.thr = ps.thr * ((bsdf * fabsf(dot(wi, n))) / pdf); // rt.h:274
                 ps.ro = prd.position;
                 ps.rd = wi;
+                ps.rng_depth = st.depth;
                 ps.depth++;
                 if (ps.depth == 10) { // MaxDepth (rt.h:166): the path is over, its last shadow ray is still pending
                     fin_pending = true; fin_L = ps.L;

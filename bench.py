@@ -51,7 +51,9 @@ def main():
     ap.add_argument("--stress-spheres", type=int, default=64)
     ap.add_argument("--stress-segments", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-spp", type=int, default=4, help="spp of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-spp", type=int, default=64, help="spp of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-threads", type=int, default=int(os.environ.get("HJR_CPU_THREADS", "16")),
+                    help="oracle threads for the CPU baseline (a 1-GPU box's CPU share is 16 cores)")
     args = ap.parse_args()
 
     import numpy as np
@@ -185,6 +187,7 @@ def main():
                 cores = len(os.sched_getaffinity(0))
             except Exception:
                 pass
+            cores = max(1, min(cores, args.cpu_threads))
             arrays = r.scene.arrays(t_frame)
             osc = ob.OracleScene(arrays, ob.MATH_LIBM)
             cspp = max(1, min(args.cpu_spp, SPP))

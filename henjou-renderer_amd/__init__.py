@@ -29,23 +29,32 @@ class Material(C.Structure):
     _fields_ = [("basecolor", C.c_float * 3), ("metallic", C.c_float), ("roughness", C.c_float),
                 ("sheen", C.c_float), ("clearcoat", C.c_float), ("ior", C.c_float),
                 ("transmission", C.c_float), ("emission", C.c_float * 3), ("is_light", C.c_int32),
-                ("ideal_specular", C.c_int32), ("is_thinfilm", C.c_int32), ("basecolor_tex", C.c_int32)]
+                ("ideal_specular", C.c_int32), ("is_thinfilm", C.c_int32), ("basecolor_tex", C.c_int32),
+                ("metallic_roughness_tex", C.c_int32), ("normal_tex", C.c_int32), ("emission_tex", C.c_int32),
+                ("_reserved", C.c_int32)]
 
 
 MATERIAL_DTYPE = np.dtype([("basecolor", "<f4", 3), ("metallic", "<f4"), ("roughness", "<f4"), ("sheen", "<f4"),
                            ("clearcoat", "<f4"), ("ior", "<f4"), ("transmission", "<f4"), ("emission", "<f4", 3),
                            ("is_light", "<i4"), ("ideal_specular", "<i4"), ("is_thinfilm", "<i4"),
-                           ("basecolor_tex", "<i4")])
+                           ("basecolor_tex", "<i4"), ("metallic_roughness_tex", "<i4"), ("normal_tex", "<i4"),
+                           ("emission_tex", "<i4"), ("_reserved", "<i4")])
+
+
+class Texture(C.Structure):
+    _fields_ = [("rgba8", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32), ("srgb", C.c_int32),
+                ("_reserved", C.c_int32)]
 
 
 class SceneView(C.Structure):
     _fields_ = [("n_vertices", C.c_uint32), ("n_triangles", C.c_uint32), ("n_instances", C.c_uint32),
                 ("n_materials", C.c_uint32), ("n_lights", C.c_uint32), ("n_animations", C.c_uint32),
+                ("n_textures", C.c_uint32), ("_reserved0", C.c_uint32),
                 ("vertices", C.c_void_p), ("normals", C.c_void_p), ("texcoords", C.c_void_p),
                 ("indices", C.c_void_p), ("material_ids", C.c_void_p), ("prim_offset", C.c_void_p),
                 ("geometry_index_offset", C.c_void_p), ("geometry_index_count", C.c_void_p),
                 ("instance_animation_id", C.c_void_p), ("materials", C.c_void_p),
-                ("light_prim_ids", C.c_void_p), ("light_prim_emission", C.c_void_p)]
+                ("light_prim_ids", C.c_void_p), ("light_prim_emission", C.c_void_p), ("textures", C.c_void_p)]
 
 
 class RenderOption(C.Structure):
@@ -114,6 +123,8 @@ def lib():
             "hjr_scene_eval_transforms": [C.c_void_p, C.c_float, C.c_void_p, C.c_void_p],
             "hjr_scene_eval_camera": [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p],
             "hjr_load_png_rgba8": [C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p],
+            "hjr_load_hdr_rgba32f": [C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p],
+            "hjr_set_sky": [C.c_void_p, C.c_void_p, C.c_int, C.c_int],
             "hjr_create": [C.c_int, C.c_void_p],
             "hjr_upload_scene": [C.c_void_p, C.c_void_p],
             "hjr_set_transforms": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32],
@@ -164,6 +175,16 @@ def load_png(path):
     w, h = C.c_int(), C.c_int()
     _check(lib().hjr_load_png_rgba8(os.fsencode(path), C.byref(p), C.byref(w), C.byref(h)), "hjr_load_png_rgba8")
     a = _np(p.value, w.value * h.value * 4, np.uint8).reshape(h.value, w.value, 4)
+    lib().hjr_free(p)
+    return a
+
+
+def load_hdr(path):
+    """Radiance .hdr -> float32 [h, w, 4] (a = 0), as HDRTexture holds it (renderer/texture.h:67-88)."""
+    p = C.c_void_p()
+    w, h = C.c_int(), C.c_int()
+    _check(lib().hjr_load_hdr_rgba32f(os.fsencode(path), C.byref(p), C.byref(w), C.byref(h)), "hjr_load_hdr_rgba32f")
+    a = _np(p.value, w.value * h.value * 4, np.float32).reshape(h.value, w.value, 4)
     lib().hjr_free(p)
     return a
 
@@ -231,6 +252,12 @@ class Scene:
             "light_prim_ids": _np(v.light_prim_ids, v.n_lights, np.uint32),
             "light_prim_emission": _np(v.light_prim_emission, v.n_lights * 3, np.float32),
         }
+        texs = []
+        if v.n_textures:
+            arr = (Texture * v.n_textures).from_address(v.textures)
+            for t in arr:
+                texs.append((_np(t.rgba8, t.width * t.height * 4, np.uint8).reshape(t.height, t.width, 4), int(t.srgb)))
+        a["textures"] = texs
         if time is not None:
             a["transforms"], a["inv_transforms"] = self.transforms(time)
         return a
@@ -268,6 +295,16 @@ class Device:
         v.n_instances = k["prim_offsets"].size
         v.n_materials = k["materials"].size
         v.n_lights = k["light_prim_ids"].size
+        texs = a.get("textures") or []
+        if texs:
+            self._keep_tex = [np.ascontiguousarray(t[0], dtype=np.uint8) for t in texs]
+            self._keep_texarr = (Texture * len(texs))()
+            for i, (t, px) in enumerate(zip(texs, self._keep_tex)):
+                self._keep_texarr[i].rgba8 = px.ctypes.data
+                self._keep_texarr[i].height, self._keep_texarr[i].width = px.shape[0], px.shape[1]
+                self._keep_texarr[i].srgb = int(t[1])
+            v.n_textures = len(texs)
+            v.textures = C.addressof(self._keep_texarr)
         for name, key in (("vertices", "vertices"), ("normals", "normals"), ("texcoords", "texcoords"), ("indices", "indices"),
                           ("material_ids", "material_ids"), ("prim_offset", "prim_offsets"), ("materials", "materials"),
                           ("light_prim_ids", "light_prim_ids"), ("light_prim_emission", "light_prim_emission")):
@@ -285,6 +322,14 @@ class Device:
             return
         a = np.ascontiguousarray(rgba, dtype=np.uint8)
         _check(lib().hjr_set_lut(self._h, a.ctypes.data, a.shape[1], a.shape[0]), "hjr_set_lut")
+
+    def set_sky(self, rgba32f):
+        """Equirect IBL (float RGBA [h, w, 4]); None restores the constant scene_sky_default sky."""
+        if rgba32f is None:
+            _check(lib().hjr_set_sky(self._h, None, 0, 0), "hjr_set_sky")
+            return
+        a = np.ascontiguousarray(rgba32f, dtype=np.float32)
+        _check(lib().hjr_set_sky(self._h, a.ctypes.data, a.shape[1], a.shape[0]), "hjr_set_sky")
 
     def render(self, params, want_aovs=True):
         """Synchronous render into host arrays (hjr_render)."""
@@ -373,6 +418,9 @@ class Renderer:
         lut_path = self.render_option.LUT_path.decode()
         if lut_path and os.path.exists(lut_path):
             self.device.set_lut(load_png(lut_path))
+        ibl = self.render_option.IBL_path.decode()
+        if self.render_option.use_IBL and ibl and os.path.exists(ibl):  # setSky (renderer.h:802-851)
+            self.device.set_sky(load_hdr(ibl))
 
     def frame_params(self, frame, spp=None, rank=0, world_size=1, flags=0):
         o = self.render_option

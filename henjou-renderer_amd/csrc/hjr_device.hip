@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -46,6 +47,9 @@ struct hjr_ctx {
     bool have_scene = false, have_frame = false;
     hjr::FrameData frame;
     DevBuf d_nodes, d_tri_geom, d_tri_shade, d_tri_inst, d_materials, d_lights, d_lut, d_work;
+    DevBuf d_texels, d_tex_desc, d_srgb_lut, d_sky;
+    int sky_w = 0, sky_h = 0;
+    uint32_t n_textures = 0;
     int lut_w = 0, lut_h = 0;
     DevBuf d_color, d_albedo, d_normal; // staging for hjr_render (host buffers)
     DevBuf d_part_color, d_part_albedo, d_part_normal; // chunk sums [n_chunks][H][W] float4
@@ -102,7 +106,7 @@ extern "C" void hjr_destroy(hjr_ctx* c)
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     for (DevBuf* b : { &c->d_nodes, &c->d_tri_geom, &c->d_tri_shade, &c->d_tri_inst, &c->d_materials, &c->d_lights, &c->d_lut,
-                       &c->d_work, &c->d_color, &c->d_albedo, &c->d_normal, &c->d_part_color, &c->d_part_albedo, &c->d_part_normal })
+                       &c->d_texels, &c->d_tex_desc, &c->d_srgb_lut, &c->d_sky, &c->d_work, &c->d_color, &c->d_albedo, &c->d_normal, &c->d_part_color, &c->d_part_albedo, &c->d_part_normal })
         b->release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -116,10 +120,26 @@ extern "C" int hjr_upload_scene(hjr_ctx* c, const hjr_scene_view* v)
     std::string err;
     if (!c->scene.set(*v, err)) { set_error("hjr_upload_scene: " + err); return HJR_ERR_ARG; }
     HIPCHK(hipSetDevice(c->device));
-    static_assert(sizeof(hjr_material) == 64, "hjr_material must be 4 x float4");
+    static_assert(sizeof(hjr_material) == HJR_MAT_F4 * 16, "hjr_material must be HJR_MAT_F4 x float4");
     if (!c->d_materials.upload(c->scene.materials.data(), c->scene.materials.size() * sizeof(hjr_material), c->stream)) {
         set_error("hjr_upload_scene: material upload failed");
         return HJR_ERR_DEVICE;
+    }
+    // textureBind (renderer.h:740-800): RGBA8 atlas + per-slot descriptors + the sRGB decode table
+    c->n_textures = (uint32_t)c->scene.textures.size();
+    if (c->n_textures) {
+        std::vector<uint32_t> desc;
+        for (auto& t : c->scene.textures) { desc.push_back(t.offset); desc.push_back(t.width); desc.push_back(t.height); desc.push_back((uint32_t)t.srgb); }
+        float lut[256];
+        for (int i = 0; i < 256; i++) {
+            double v = (double)i / 255.0;
+            lut[i] = (float)(v <= 0.04045 ? v / 12.92 : pow((v + 0.055) / 1.055, 2.4));
+        }
+        if (!c->d_texels.upload(c->scene.texels.data(), c->scene.texels.size() * 4, c->stream) ||
+            !c->d_tex_desc.upload(desc.data(), desc.size() * 4, c->stream) || !c->d_srgb_lut.upload(lut, sizeof(lut), c->stream)) {
+            set_error("hjr_upload_scene: texture upload failed");
+            return HJR_ERR_DEVICE;
+        }
     }
     HIPCHK(hipStreamSynchronize(c->stream));
     c->have_scene = true;
@@ -166,6 +186,17 @@ extern "C" int hjr_set_lut(hjr_ctx* c, const uint8_t* rgba, int w, int h)
 
 // persistent grid = resident workgroups only: CUs x (workgroups the kernel's VGPR/LDS budget admits per CU), capped by the
 // number of wavefront-sized batches of work; HJR_BLOCKS_PER_CU overrides the occupancy query
+extern "C" int hjr_set_sky(hjr_ctx* c, const float* rgba, int w, int h)
+{
+    if (!c) { set_error("hjr_set_sky: null context"); return HJR_ERR_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    if (!rgba || w <= 0 || h <= 0) { c->sky_w = c->sky_h = 0; return HJR_OK; }
+    if (!c->d_sky.upload(rgba, (size_t)w * (size_t)h * 16, c->stream)) { set_error("hjr_set_sky: upload failed"); return HJR_ERR_DEVICE; }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->sky_w = w; c->sky_h = h;
+    return HJR_OK;
+}
+
 template <int I, bool S, int W> static int launch_mem(const hjr_ctx* c, const KParams& kp, uint64_t n_items, hipStream_t st);
 // lds_mode: 0 = BVH4 read from memory, 1 = BVH2 staged in LDS with 32-bit stack entries, 2 = with 16-bit entries, 3 = BVH2 from memory
 template <int I, bool S, bool S16, bool A> static int launch_lds2(const hjr_ctx* c, const KParams& kp, uint64_t n_items, hipStream_t st)
@@ -182,7 +213,8 @@ template <int I, bool S, bool S16, bool A> static int launch_lds2(const hjr_ctx*
 // the albedo / normal AOV sums cost 6 VGPRs per lane: a separate instantiation for callers that only want aov_color
 template <int I, bool S, bool S16> static int launch_lds(const hjr_ctx* c, const KParams& kp, uint64_t n_items, hipStream_t st)
 {
-    return (kp.aov_albedo || kp.aov_normal) ? launch_lds2<I, S, S16, true>(c, kp, n_items, st) : launch_lds2<I, S, S16, false>(c, kp, n_items, st);
+    const bool full = kp.aov_albedo || kp.aov_normal || kp.tex_desc || kp.sky_tex;
+    return full ? launch_lds2<I, S, S16, true>(c, kp, n_items, st) : launch_lds2<I, S, S16, false>(c, kp, n_items, st);
 }
 template <int I, bool S> static int launch(const hjr_ctx* c, const KParams& kp, uint64_t n_items, int lds_mode, hipStream_t st)
 {
@@ -264,6 +296,9 @@ static int render_impl(hjr_ctx* c, const hjr_params* p, void* d_color, void* d_a
     kp.lights = (const float4*)c->d_lights.p;
     kp.lut = (c->lut_w > 0) ? (const uchar4*)c->d_lut.p : nullptr;
     kp.lut_w = c->lut_w; kp.lut_h = c->lut_h;
+    if (c->n_textures) { kp.texels = (const uchar4*)c->d_texels.p; kp.tex_desc = (const uint4*)c->d_tex_desc.p; kp.srgb_lut = (const float*)c->d_srgb_lut.p; }
+    if (c->sky_w > 0) { kp.sky_tex = (const float4*)c->d_sky.p; kp.sky_w = c->sky_w; kp.sky_h = c->sky_h; }
+    kp.ibl_intensity = p->ibl_intensity;
     kp.aov_color = (float4*)d_color; kp.aov_albedo = (float4*)d_albedo; kp.aov_normal = (float4*)d_normal;
     kp.queue_head = (unsigned int*)c->d_work.p;
     kp.stats = (unsigned long long*)((char*)c->d_work.p + 16);

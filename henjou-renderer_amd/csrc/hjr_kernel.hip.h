@@ -27,12 +27,17 @@ struct KParams {
     const float4* materials;
     const float4* lights;
     const uchar4* lut;
+    const uchar4* texels;    // RGBA8 atlas of all material textures
+    const uint4* tex_desc;   // per texture slot: (texel offset, width, height, srgb)
+    const float* srgb_lut;   // 256-entry sRGB -> linear table (host-computed)
+    const float4* sky_tex;   // equirect IBL (float4), null = constant sky
     float4* aov_color;
     float4* aov_albedo;
     float4* aov_normal;
     unsigned int* queue_head;
     unsigned long long* stats;
     int lut_w, lut_h;
+    int sky_w, sky_h;
     uint32_t n_lights;
     uint32_t width, height, spp, frame, seed, integrator;
     uint32_t tiles_x, n_owned_items; // items = owned tiles * n_chunks * 64
@@ -46,6 +51,7 @@ struct KParams {
     float cam_pos[3], cam_dir[3], cam_up[3], cam_right[3];
     float cam_f;
     float sky[3]; // scene_sky_default * ibl_intensity
+    float ibl_intensity;
 };
 
 // ------------------------------------------------------------------ kernel/cmj.h
@@ -180,6 +186,56 @@ HD f3 lut_fetch(const KParams& P, float u, float v)
     r.y = w00 * ((float)c00.y * k) + w10 * ((float)c10.y * k) + w01 * ((float)c01.y * k) + w11 * ((float)c11.y * k);
     r.z = w00 * ((float)c00.z * k) + w10 * ((float)c10.z * k) + w01 * ((float)c01.z * k) + w11 * ((float)c11.z * k);
     return r;
+}
+
+// ------------------------------------------------------------------ material textures (renderer.h:740-800) and equirect sky (renderer.h:802-851)
+// Build-defined sampling (the closest-hit / miss sources are missing): wrap, bilinear with CUDA's 1.8 fixed-point weights,
+// sRGB -> linear per texel before filtering for TexType::sRGB; sky (u, v) = (atan2(d.z, d.x) / 2pi + 0.5, acos(d.y) / pi).
+struct Bilin { int i0, i1, j0, j1; float w00, w10, w01, w11; };
+HD Bilin bilin(float u, float v, int w, int h)
+{
+    Bilin b;
+    float x = u * (float)w - 0.5f, y = v * (float)h - 0.5f;
+    float fx = floorf(x), fy = floorf(y);
+    float ax = floorf((x - fx) * 256.0f + 0.5f) * (1.0f / 256.0f);
+    float ay = floorf((y - fy) * 256.0f + 0.5f) * (1.0f / 256.0f);
+    b.i0 = (int)fx % w; if (b.i0 < 0) b.i0 += w;
+    b.j0 = (int)fy % h; if (b.j0 < 0) b.j0 += h;
+    b.i1 = (b.i0 + 1) % w; b.j1 = (b.j0 + 1) % h;
+    b.w00 = (1.0f - ax) * (1.0f - ay); b.w10 = ax * (1.0f - ay); b.w01 = (1.0f - ax) * ay; b.w11 = ax * ay;
+    return b;
+}
+HD f3 tex_fetch(const KParams& P, int slot, float u, float v)
+{
+    const uint4 d = P.tex_desc[slot];
+    const int w = (int)d.y, h = (int)d.z;
+    const Bilin b = bilin(u, v, w, h);
+    const uchar4* t = P.texels + d.x;
+    const uchar4 c00 = t[b.j0 * w + b.i0], c10 = t[b.j0 * w + b.i1], c01 = t[b.j1 * w + b.i0], c11 = t[b.j1 * w + b.i1];
+    f3 r;
+    if (d.w) {
+        const float* L = P.srgb_lut;
+        r.x = b.w00 * L[c00.x] + b.w10 * L[c10.x] + b.w01 * L[c01.x] + b.w11 * L[c11.x];
+        r.y = b.w00 * L[c00.y] + b.w10 * L[c10.y] + b.w01 * L[c01.y] + b.w11 * L[c11.y];
+        r.z = b.w00 * L[c00.z] + b.w10 * L[c10.z] + b.w01 * L[c01.z] + b.w11 * L[c11.z];
+    } else {
+        const float k = 1.0f / 255.0f;
+        r.x = b.w00 * ((float)c00.x * k) + b.w10 * ((float)c10.x * k) + b.w01 * ((float)c01.x * k) + b.w11 * ((float)c11.x * k);
+        r.y = b.w00 * ((float)c00.y * k) + b.w10 * ((float)c10.y * k) + b.w01 * ((float)c01.y * k) + b.w11 * ((float)c11.y * k);
+        r.z = b.w00 * ((float)c00.z * k) + b.w10 * ((float)c10.z * k) + b.w01 * ((float)c01.z * k) + b.w11 * ((float)c11.z * k);
+    }
+    return r;
+}
+HD f3 sky_fetch(const KParams& P, f3 d)
+{
+    const float u = p_atan2(d.z, d.x) * 0.15915494309189533577f + 0.5f;
+    const float v = p_acos(clampf(d.y, -1.0f, 1.0f)) * HJ_INV_PI;
+    const int w = P.sky_w, h = P.sky_h;
+    const Bilin b = bilin(u, v, w, h);
+    const float4 c00 = P.sky_tex[b.j0 * w + b.i0], c10 = P.sky_tex[b.j0 * w + b.i1], c01 = P.sky_tex[b.j1 * w + b.i0], c11 = P.sky_tex[b.j1 * w + b.i1];
+    return V(b.w00 * c00.x + b.w10 * c10.x + b.w01 * c01.x + b.w11 * c11.x,
+             b.w00 * c00.y + b.w10 * c10.y + b.w01 * c01.y + b.w11 * c11.y,
+             b.w00 * c00.z + b.w10 * c10.z + b.w01 * c01.z + b.w11 * c11.z);
 }
 
 // ------------------------------------------------------------------ DisneyBRDF (kernel/disneyBRDF.h:16-327)
@@ -718,12 +774,13 @@ struct HitInfo { // the Payload fields the integrators read (kernel/Payload.h:12
 };
 
 // __closesthit__ch / __miss__ms for a finished closest-hit traversal
-template <bool STATS>
-HD void hit_program(const KParams& P, const float4* tris, const Hit& h, HitInfo& prd, unsigned long long* lc)
+template <bool STATS, bool FULL>
+HD void hit_program(const KParams& P, const float4* tris, const Hit& h, const f3 rd, HitInfo& prd, unsigned long long* lc)
 {
     if (h.prim == 0xffffffffu) { // __miss__ms: constant sky (use_IBL = false: 1x1 texel scene_sky_default, renderer.h:802-851) * ibl_intensity
         prd.is_hit = false; prd.is_light = false;
-        prd.emission = V(P.sky[0], P.sky[1], P.sky[2]);
+        if (FULL && P.sky_tex) prd.emission = sky_fetch(P, rd) * P.ibl_intensity; // tex2D(ibl_texture, u, v) * ibl_intensity
+        else prd.emission = V(P.sky[0], P.sky[1], P.sky[2]);
         prd.position = V1(0.0f); prd.normal = V1(0.0f);
         prd.surf.basecolor = V1(0.0f); // Payload default (Payload.h:25)
         prd.surf.metallic = 0.0f; prd.surf.roughness = 0.0f; prd.surf.sheen = 0.0f; prd.surf.clearcoat = 0.0f; prd.surf.ior = 1.0f;
@@ -746,6 +803,19 @@ HD void hit_program(const KParams& P, const float4* tris, const Hit& h, HitInfo&
     prd.surf.basecolor = V(m0.x, m0.y, m0.z);
     prd.surf.metallic = m0.w;
     prd.surf.roughness = m1.x; prd.surf.sheen = m1.y; prd.surf.clearcoat = m1.z; prd.surf.ior = m1.w;
+    if (FULL && P.tex_desc) { // material textures: factor x texel (glTF 2.0 semantics; build-defined)
+        const int bc_tex = (int)f2bits(m3.w), mr_tex = (int)f2bits(m[4].x);
+        if (bc_tex >= 0 || mr_tex >= 0) {
+            const float tu = s0.w * w0 + s2.w * h.b1 + s3.y * h.b2; // uv0 = (s0.w, s1.w), uv1 = (s2.w, s3.x), uv2 = (s3.y, s3.z)
+            const float tv = s1.w * w0 + s3.x * h.b1 + s3.z * h.b2;
+            if (bc_tex >= 0) prd.surf.basecolor = prd.surf.basecolor * tex_fetch(P, bc_tex, tu, tv);
+            if (mr_tex >= 0) {
+                const f3 e = tex_fetch(P, mr_tex, tu, tv);
+                prd.surf.roughness = prd.surf.roughness * e.y;
+                prd.surf.metallic = prd.surf.metallic * e.z;
+            }
+        }
+    }
     prd.emission = V(m2.y, m2.z, m2.w);
     prd.is_light = f2bits(m3.x) != 0;
     prd.surf.is_specular = f2bits(m3.y) != 0;
@@ -755,14 +825,14 @@ HD void hit_program(const KParams& P, const float4* tris, const Hit& h, HitInfo&
 }
 
 // RayTrace (rt.h:43-69): stand-alone closest-hit query (used by MIS' BSDF-sampled light ray)
-template <bool STATS, int WIDTH, int BLOCK, typename ST>
+template <bool STATS, bool FULL, int WIDTH, int BLOCK, typename ST>
 HD void ray_trace(const KParams& P, const float4* nodes, const float4* tris, f3 o, f3 d, HitInfo& prd, ST* stack, unsigned long long* lc)
 {
     Hit h;
     Counters c; c.box = 0; c.tri = 0;
     traverse<false, STATS, WIDTH, BLOCK, ST>(nodes, tris, o, d, 0.001f, 1e16f, h, stack, c);
     if (STATS) { lc[1] += 1; lc[3] += c.box; lc[4] += c.tri; }
-    hit_program<STATS>(P, tris, h, prd, lc);
+    hit_program<STATS, FULL>(P, tris, h, d, prd, lc);
 }
 
 // light_sample (kernel/light_sample.h:9-75) on the per-frame light table
@@ -836,6 +906,8 @@ HD void start_path(const KParams& P, PathState& ps, uint32_t px, uint32_t py, ui
 // workgroup of BLOCK threads per CU shares the copy.  Chosen by the host when the scene fits (hjr_device.hip).
 extern __shared__ float4 hjr_smem[];
 
+// AOVS = the "full" variant: albedo / normal AOV sums, material textures and the equirect sky texture; the lean variant
+// (colour only, untextured scene, constant sky) saves registers and is what the headline benchmark runs
 template <int INTEGRATOR, bool STATS, int BLOCK, bool LDSBVH, bool STACK16, int WIDTH, bool AOVS>
 __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_render_kernel(const KParams P)
 {
@@ -989,7 +1061,7 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
 
         if (tracing) {
             HitInfo prd;
-            hit_program<STATS>(P, tris, h, prd, lc);
+            hit_program<STATS, AOVS>(P, tris, h, ps.rd, prd, lc);
             if (AOVS && ps.depth == 0) { sumA = sumA + prd.surf.basecolor; sumN = sumN + prd.normal; } // rt.h:191-194
             if (!prd.is_hit || prd.is_light) {
                 // NEE / MIS count emission only at depth 0 (rt.h:196-208, 318-330); Pathtrace always (rt.h:118-126)
@@ -1057,7 +1129,7 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
                     const f3 wi = local_to_world(local_wi, t, n, b);
                     const float cosine1 = absdot(wi, n);
                     HitInfo lh;
-                    ray_trace<STATS, WIDTH, BLOCK, ST>(P, nodes, tris, prd.position, wi, lh, stack, lc);
+                    ray_trace<STATS, AOVS, WIDTH, BLOCK, ST>(P, nodes, tris, prd.position, wi, lh, stack, lc);
                     if (lh.is_hit) {
                         if (lh.is_light) {
                             const float cosine2 = absdot(-wi, lh.normal);

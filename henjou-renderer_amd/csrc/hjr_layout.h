@@ -34,8 +34,8 @@
 /* Shading record by GLOBAL prim id, 64 B = 4 x float4: world normals (each normalised, __closesthit__ch) + uvs + material.
  *   s0 = (n0.xyz uv0.x) s1 = (n1.xyz uv0.y) s2 = (n2.xyz uv1.x) s3 = (uv1.y uv2.x uv2.y material_id bits) */
 #define HJR_SHADE_F4 4
-/* Material, 64 B = hjr_material verbatim (include/henjou_hip.h). */
-#define HJR_MAT_F4 4
+/* Material, 80 B = hjr_material verbatim (include/henjou_hip.h); m4 = (metallic_roughness_tex, normal_tex, emission_tex, -) */
+#define HJR_MAT_F4 5
 /* Light triangle, 96 B = 6 x float4 (light_sample.h:43-72 hoisted to once per frame):
  *   l0 = (v0.xyz pdf)  l1 = (v1.xyz em.x)  l2 = (v2.xyz em.y)  l3 = (n0.xyz em.z)  l4 = (n1.xyz 0)  l5 = (n2.xyz 0)
  *   v*: transform_position(transforms[inst]); n*: transform_normal(inv_transforms[inst]) (NOT normalised);

@@ -137,3 +137,23 @@ HD float p_pow(float x, float y)
     return p_exp(t);
 }
 HD float p_pow5(float x) { float x2 = x * x; float x4 = x2 * x2; return x4 * x; }
+// Cephes atanf on [0, inf) + quadrant logic (equirect sky lookup only)
+HD float p_atan_pos(float x)
+{
+    float y0;
+    if (x > 2.414213562373095f) { y0 = 1.57079632679489661923f; x = -(1.0f / x); }
+    else if (x > 0.4142135623730950f) { y0 = 0.78539816339744830962f; x = (x - 1.0f) / (x + 1.0f); }
+    else y0 = 0.0f;
+    float z = x * x;
+    float p = fmaf(fmaf(fmaf(8.05374449538e-2f, z, -1.38776856032e-1f), z, 1.99777106478e-1f), z, -3.33329491539e-1f);
+    return y0 + fmaf(p * z, x, x);
+}
+HD float p_atan2(float y, float x)
+{
+    if (x != x || y != y) return x + y;
+    if (y == 0.0f) return (x >= 0.0f && !(f2bits(x) >> 31)) ? y : copysignf(HJ_PI, y);
+    if (x == 0.0f) return copysignf(1.57079632679489661923f, y);
+    float a = p_atan_pos(fabsf(y / x));
+    if (x < 0.0f) a = HJ_PI - a;
+    return copysignf(a, y);
+}

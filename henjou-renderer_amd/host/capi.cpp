@@ -15,6 +15,7 @@ void set_error(const std::string& s) { g_err = s; }
 bool write_png(const std::string& path, const uint8_t* rgba, uint32_t w, uint32_t h, bool flip_y, std::string& err);
 bool read_png_rgba8(const std::string& path, std::vector<uint8_t>& rgba, int& w, int& h, std::string& err);
 bool write_pfm(const std::string& path, const float* rgba, uint32_t w, uint32_t h, std::string& err);
+bool read_hdr_rgba32f(const std::string& path, std::vector<float>& rgba, int& w, int& h, std::string& err);
 void float4_to_srgb8(const float* rgba, uint8_t* out, uint32_t n);
 } // namespace hjr
 using hjr::set_error;
@@ -76,6 +77,8 @@ extern "C" int hjr_scene_get_view(const hjr_scene* s, hjr_scene_view* v)
     v->materials = d.materials.data();
     v->light_prim_ids = d.light_prim_ids.data();
     v->light_prim_emission = d.light_prim_emission.empty() ? nullptr : &d.light_prim_emission[0].x;
+    v->n_textures = (uint32_t)d.texture_views.size();
+    v->textures = d.texture_views.data();
     return HJR_OK;
 }
 
@@ -105,6 +108,21 @@ extern "C" int hjr_load_png_rgba8(const char* path, uint8_t** rgba, int* w, int*
     *rgba = (uint8_t*)malloc(px.size());
     if (!*rgba) { set_error("out of memory"); return HJR_ERR_ARG; }
     memcpy(*rgba, px.data(), px.size());
+    return HJR_OK;
+}
+
+extern "C" int hjr_load_hdr_rgba32f(const char* path, float** rgba, int* w, int* h)
+{
+    if (!path || !rgba || !w || !h) { set_error("hjr_load_hdr_rgba32f: null argument"); return HJR_ERR_ARG; }
+    std::vector<float> px;
+    std::string err;
+    if (!hjr::read_hdr_rgba32f(path, px, *w, *h, err)) {
+        set_error(err);
+        return err.rfind("cannot open", 0) == 0 ? HJR_ERR_IO : HJR_ERR_PARSE;
+    }
+    *rgba = (float*)malloc(px.size() * sizeof(float));
+    if (!*rgba) { set_error("out of memory"); return HJR_ERR_ARG; }
+    memcpy(*rgba, px.data(), px.size() * sizeof(float));
     return HJR_OK;
 }
 
@@ -142,7 +160,6 @@ extern "C" int hjr_render_file(const char* render_option_json, int device)
     int rc = hjr_load_render_option(render_option_json, &opt);
     if (rc != HJR_OK) return rc;
     if (opt.render_mode != HJR_MODE_DEFAULT) { set_error("hjr_render_file: only Render_mode \"Default\" is supported (no OptiX denoiser on this platform)"); return HJR_ERR_ARG; }
-    if (opt.use_IBL) { set_error("hjr_render_file: use_IBL=true (equirect HDR sky) is not implemented yet; the constant scene_sky_default sky is"); return HJR_ERR_ARG; }
     hjr_scene* scene = nullptr;
     rc = hjr_scene_load_gltf(opt.gltf_path, opt.gltf_name, &opt, &scene);
     if (rc != HJR_OK) return rc;
@@ -163,6 +180,14 @@ extern "C" int hjr_render_file(const char* render_option_json, int device)
             for (uint32_t i = 0; i < view.n_materials; i++) needs = needs || view.materials[i].is_thinfilm;
             if (needs) rc = HJR_ERR_IO; // hjr_last_error() already holds the PNG error
         }
+    }
+    if (rc == HJR_OK && opt.use_IBL) { // setSky (renderer.h:802-851): a missing / undecodable HDR falls back to the 1x1 scene_sky_default texel (texture.h:89-98)
+        float* sky = nullptr;
+        int sw = 0, sh = 0;
+        if (hjr_load_hdr_rgba32f(opt.IBL_path, &sky, &sw, &sh) == HJR_OK) {
+            rc = hjr_set_sky(ctx, sky, sw, sh);
+            hjr_free(sky);
+        } else fprintf(stderr, "[henjou] %s NOT FOUND: using scene_sky_default\n", opt.IBL_path);
     }
     std::vector<float> m((size_t)view.n_instances * 12), inv((size_t)view.n_instances * 12);
     const size_t npx = (size_t)opt.image_width * opt.image_height;

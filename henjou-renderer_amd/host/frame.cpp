@@ -37,6 +37,20 @@ bool SceneCopy::set(const hjr_scene_view& v, std::string& err)
     if (v.n_instances && prim_offset[0] != 0) { err = "prim_offset[0] must be 0"; return false; }
     for (uint32_t l = 0; l < v.n_lights; l++)
         if (light_prim_ids[l] >= v.n_triangles) { err = "light prim id out of range"; return false; }
+    textures.clear(); texels.clear();
+    if (v.n_textures && !v.textures) { err = "null texture array"; return false; }
+    for (uint32_t t = 0; t < v.n_textures; t++) {
+        const hjr_texture& tx = v.textures[t];
+        if (!tx.rgba8 || tx.width == 0 || tx.height == 0 || (uint64_t)tx.width * tx.height > (1u << 28)) { err = "bad texture"; return false; }
+        Tex d = { (uint32_t)texels.size(), tx.width, tx.height, tx.srgb };
+        const uint32_t* px = reinterpret_cast<const uint32_t*>(tx.rgba8);
+        texels.insert(texels.end(), px, px + (size_t)tx.width * tx.height);
+        textures.push_back(d);
+    }
+    for (uint32_t m = 0; m < v.n_materials; m++) {
+        const hjr_material& mt = materials[m];
+        if (mt.basecolor_tex >= (int)v.n_textures || mt.metallic_roughness_tex >= (int)v.n_textures) { err = "material texture slot out of range"; return false; }
+    }
     return true;
 }
 

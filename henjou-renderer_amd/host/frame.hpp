@@ -29,6 +29,9 @@ struct SceneCopy {
     std::vector<float> vertices, normals, texcoords, light_prim_emission;
     std::vector<uint32_t> indices, material_ids, prim_offset, light_prim_ids;
     std::vector<hjr_material> materials;
+    struct Tex { uint32_t offset, width, height; int srgb; }; // offset in texels into `texels`
+    std::vector<Tex> textures;
+    std::vector<uint32_t> texels; // RGBA8 atlas, all textures back to back
     uint32_t n_triangles = 0, n_instances = 0;
     bool set(const hjr_scene_view& v, std::string& err);
 };

@@ -143,6 +143,81 @@ bool read_png_rgba8(const std::string& path, std::vector<uint8_t>& rgba, int& w,
     return true;
 }
 
+// Radiance .hdr (RGBE, flat or new-style RLE scanlines, -Y H +X W) -> float RGBA with a = 0, as HDRTexture builds it from
+// stbi_loadf (renderer/texture.h:67-88).  RGBE -> float: m * 2^(e - 136), e == 0 -> 0 (stb_image's conversion).
+bool read_hdr_rgba32f(const std::string& path, std::vector<float>& rgba, int& w, int& h, std::string& err)
+{
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) { err = "cannot open " + path; return false; }
+    std::vector<unsigned char> buf;
+    unsigned char tmp[65536];
+    size_t n;
+    while ((n = fread(tmp, 1, sizeof(tmp), f)) > 0) buf.insert(buf.end(), tmp, tmp + n);
+    fclose(f);
+    size_t pos = 0;
+    auto getline = [&](std::string& line) {
+        line.clear();
+        while (pos < buf.size() && buf[pos] != '\n') line += (char)buf[pos++];
+        if (pos < buf.size()) pos++;
+    };
+    std::string line;
+    getline(line);
+    if (line.rfind("#?RADIANCE", 0) != 0 && line.rfind("#?RGBE", 0) != 0) { err = path + ": not a Radiance HDR file"; return false; }
+    bool fmt = false;
+    for (;;) {
+        if (pos >= buf.size()) { err = path + ": truncated header"; return false; }
+        getline(line);
+        if (line.empty()) break;
+        if (line == "FORMAT=32-bit_rle_rgbe") fmt = true;
+    }
+    if (!fmt) { err = path + ": unsupported HDR format"; return false; }
+    getline(line);
+    int W = 0, H = 0;
+    if (sscanf(line.c_str(), "-Y %d +X %d", &H, &W) != 2 || W <= 0 || H <= 0 || W > 65535 || H > 65535) { err = path + ": unsupported HDR orientation"; return false; }
+    w = W; h = H;
+    rgba.assign((size_t)W * H * 4, 0.0f);
+    std::vector<unsigned char> scan((size_t)W * 4);
+    auto put = [&](int y) {
+        for (int x = 0; x < W; x++) {
+            const unsigned char* p = &scan[(size_t)x * 4];
+            float* o = &rgba[((size_t)y * W + x) * 4];
+            if (p[3] != 0) {
+                float sc = ldexpf(1.0f, (int)p[3] - 136);
+                o[0] = p[0] * sc; o[1] = p[1] * sc; o[2] = p[2] * sc;
+            }
+        }
+    };
+    for (int y = 0; y < H; y++) {
+        if (pos + 4 > buf.size()) { err = path + ": truncated pixel data"; return false; }
+        if (W < 8 || W >= 32768 || buf[pos] != 2 || buf[pos + 1] != 2 || (buf[pos + 2] & 0x80)) { // flat scanline
+            if (pos + (size_t)W * 4 > buf.size()) { err = path + ": truncated pixel data"; return false; }
+            memcpy(scan.data(), &buf[pos], (size_t)W * 4);
+            pos += (size_t)W * 4;
+        } else {
+            if ((((int)buf[pos + 2]) << 8 | buf[pos + 3]) != W) { err = path + ": bad RLE scanline width"; return false; }
+            pos += 4;
+            for (int c = 0; c < 4; c++) {
+                int x = 0;
+                while (x < W) {
+                    if (pos >= buf.size()) { err = path + ": truncated RLE data"; return false; }
+                    int count = buf[pos++];
+                    if (count > 128) {
+                        count -= 128;
+                        if (pos >= buf.size() || x + count > W) { err = path + ": corrupt RLE run"; return false; }
+                        unsigned char v = buf[pos++];
+                        for (int k = 0; k < count; k++) scan[(size_t)(x++) * 4 + c] = v;
+                    } else {
+                        if (count == 0 || pos + (size_t)count > buf.size() || x + count > W) { err = path + ": corrupt RLE literal"; return false; }
+                        for (int k = 0; k < count; k++) scan[(size_t)(x++) * 4 + c] = buf[pos++];
+                    }
+                }
+            }
+        }
+        put(y);
+    }
+    return true;
+}
+
 bool write_pfm(const std::string& path, const float* rgba, uint32_t w, uint32_t h, std::string& err)
 {
     FILE* f = fopen(path.c_str(), "wb");

@@ -12,6 +12,8 @@
 
 namespace hjr {
 
+bool read_png_rgba8(const std::string& path, std::vector<uint8_t>& rgba, int& w, int& h, std::string& err);
+
 static bool read_file(const std::string& path, std::string& out)
 {
     std::ifstream ifs(path, std::ios::binary);
@@ -276,8 +278,10 @@ double arr_or(const Json* a, size_t i, double d)
     return (a && a->is_array() && i < a->size() && a->at(i).is_number()) ? a->at(i).num : d;
 }
 
-// loadTexture(textures, known_tex, name, ...) — texture_load.h:7-20: de-duplicate by file name, return slot
-int texture_slot(SceneData& sc, std::map<std::string, int>& known, const Model& m, const Json* texinfo)
+// loadTexture(textures, known_tex, name, modelpath, type) — texture_load.h:7-20: de-duplicate by file name, return slot.
+// Texture(filename, type) (renderer/texture.h:22-38) decodes with stbi_load(..., STBI_rgb_alpha); here: the PNG decoder of
+// image_io.cpp (JPEG is not supported and is reported as an error instead of the reference's silent "NOT FOUND").
+int texture_slot(SceneData& sc, std::map<std::string, int>& known, const Model& m, const Json* texinfo, const std::string& dir, bool srgb)
 {
     if (!texinfo) return -1;
     int idx = (int)texinfo->int_or("index", -1);
@@ -288,8 +292,15 @@ int texture_slot(SceneData& sc, std::map<std::string, int>& known, const Model& 
     std::string uri = m.json.at("images").at((size_t)src).string_or("uri", "");
     auto it = known.find(uri);
     if (it != known.end()) return it->second;
+    if (uri == "") return -1;
     int slot = (int)sc.texture_files.size();
+    SceneData::TexturePixels px;
+    int w = 0, h = 0;
+    std::string err;
+    if (!read_png_rgba8(dir + "/" + uri, px.rgba, w, h, err)) throw JsonError("texture " + uri + ": " + err);
+    px.width = (uint32_t)w; px.height = (uint32_t)h; px.srgb = srgb ? 1 : 0;
     sc.texture_files.push_back(uri);
+    sc.textures.push_back(std::move(px));
     known[uri] = slot;
     return slot;
 }
@@ -316,14 +327,15 @@ bool load_gltf(const std::string& dir, const std::string& file, SceneData& sc, h
                 memset(&mat, 0, sizeof(mat));
                 const Json* bcf = pbr ? pbr->find("baseColorFactor") : nullptr;
                 for (int k = 0; k < 3; k++) mat.basecolor[k] = float(arr_or(bcf, (size_t)k, 1.0));
-                mat.basecolor_tex = texture_slot(sc, known_tex, m, pbr ? pbr->find("baseColorTexture") : nullptr);
+                mat.basecolor_tex = texture_slot(sc, known_tex, m, pbr ? pbr->find("baseColorTexture") : nullptr, dir, true);
                 mat.roughness = float(pbr ? pbr->number_or("roughnessFactor", 1.0) : 1.0);
-                (void)texture_slot(sc, known_tex, m, pbr ? pbr->find("metallicRoughnessTexture") : nullptr);
+                mat.metallic_roughness_tex = texture_slot(sc, known_tex, m, pbr ? pbr->find("metallicRoughnessTexture") : nullptr, dir, false);
                 mat.metallic = float(pbr ? pbr->number_or("metallicFactor", 1.0) : 1.0);
                 const Json* em = material.find("emissiveFactor");
                 for (int k = 0; k < 3; k++) mat.emission[k] = float(arr_or(em, (size_t)k, 0.0));
                 mat.is_light = (mat.emission[0] + mat.emission[1] + mat.emission[2] > 0.0) ? 1 : 0; // :1162-1167 (before strength)
-                (void)texture_slot(sc, known_tex, m, material.find("normalTexture"));
+                mat.normal_tex = texture_slot(sc, known_tex, m, material.find("normalTexture"), dir, false);
+                mat.emission_tex = -1; // gltfloader.h:1159
                 mat.sheen = 0;
                 mat.clearcoat = 0;
                 mat.transmission = 0;
@@ -506,6 +518,7 @@ bool load_gltf(const std::string& dir, const std::string& file, SceneData& sc, h
             }
         }
         sc.animations = animation;
+        for (auto& t : sc.textures) sc.texture_views.push_back(hjr_texture{ t.rgba.data(), t.width, t.height, t.srgb, 0 });
         for (size_t i = 0; i < sc.instances.size(); i++) {
             sc.geo_index_offset.push_back(sc.geometries[sc.instances[i].geometry_id].index_offset);
             sc.geo_index_count.push_back(sc.geometries[sc.instances[i].geometry_id].index_count);

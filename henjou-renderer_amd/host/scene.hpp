@@ -142,7 +142,10 @@ struct SceneData { // scene.h:19-36
     std::vector<float2_> texcoords;
     std::vector<hjr_material> materials;
     std::vector<std::string> material_names;
-    std::vector<std::string> texture_files; // de-duplicated by name (texture_load.h:7-20); pixels are not loaded yet
+    std::vector<std::string> texture_files; // de-duplicated by name (texture_load.h:7-20)
+    struct TexturePixels { std::vector<uint8_t> rgba; uint32_t width = 0, height = 0; int srgb = 1; };
+    std::vector<TexturePixels> textures;    // Texture (renderer/texture.h:16-39), same slots as texture_files
+    std::vector<hjr_texture> texture_views;
     std::vector<uint32_t> light_prim_ids;
     std::vector<float3_> light_prim_emission;
     std::vector<Animation> animations;

@@ -44,8 +44,21 @@ typedef struct hjr_material {
     int32_t is_light;
     int32_t ideal_specular;
     int32_t is_thinfilm;
-    int32_t basecolor_tex;   /* -1 = none */
-} hjr_material;              /* 64 bytes */
+    int32_t basecolor_tex;   /* texture slot or -1 (Material.base_color_tex, TexType::sRGB, gltfloader.h:1133-1140) */
+    int32_t metallic_roughness_tex; /* slot or -1 (metallic_tex == roughness_tex, NonColor, gltfloader.h:1144-1156): G = roughness, B = metallic */
+    int32_t normal_tex;      /* slot or -1; carried, not sampled (no tangent frame on this path) */
+    int32_t emission_tex;    /* always -1 on the glTF path (gltfloader.h:1159) */
+    int32_t _reserved;
+} hjr_material;              /* 80 bytes */
+
+/* Texture(filename, type) — renderer/texture.h:16-39: 8-bit RGBA, bound wrap + linear + normalised coords, sRGB decode
+ * unless NonColor (renderer.h:740-800). */
+typedef struct hjr_texture {
+    const uint8_t* rgba8;    /* width * height * 4, row 0 = top image row */
+    uint32_t width, height;
+    int32_t srgb;            /* 1: TexType::sRGB, 0: NonColor */
+    int32_t _reserved;
+} hjr_texture;
 
 /* Borrowed, read-only view of SceneData (renderer/scene.h:19-36).  The library copies on upload. */
 typedef struct hjr_scene_view {
@@ -55,6 +68,8 @@ typedef struct hjr_scene_view {
     uint32_t n_materials;
     uint32_t n_lights;       /* emissive triangles (gltfloader.h:1496-1500) */
     uint32_t n_animations;   /* == number of glTF nodes */
+    uint32_t n_textures;     /* SceneData.textures (de-duplicated by file name, texture_load.h:7-20) */
+    uint32_t _reserved0;
     const float*    vertices;            /* float3 x n_vertices, object space */
     const float*    normals;             /* float3 x n_vertices */
     const float*    texcoords;           /* float2 x n_vertices */
@@ -67,6 +82,7 @@ typedef struct hjr_scene_view {
     const hjr_material* materials;
     const uint32_t* light_prim_ids;      /* n_lights, global triangle ids */
     const float*    light_prim_emission; /* float3 x n_lights */
+    const hjr_texture* textures;         /* n_textures */
 } hjr_scene_view;
 
 /* Mirror of RenderOption (renderer/render_option.h:45-84). */
@@ -144,6 +160,8 @@ int hjr_scene_eval_transforms(const hjr_scene*, float time, float* transforms12,
 int hjr_scene_eval_camera(const hjr_scene*, const hjr_render_option*, float time, hjr_camera* out);
 /* Texture(LUT_path, NonColor) — renderer/texture.h:16-39, loader/texture_load.h:7-20: 8-bit RGBA, caller frees with hjr_free */
 int hjr_load_png_rgba8(const char* path, uint8_t** rgba, int* w, int* h);
+/* HDRTexture(filename, background) — renderer/texture.h:67-100 (stbi_loadf): Radiance .hdr (RGBE) -> float RGBA (a = 0), caller frees with hjr_free */
+int hjr_load_hdr_rgba32f(const char* path, float** rgba, int* w, int* h);
 void hjr_free(void*);
 
 /* ---------------- device side: replaces context/GAS/IAS/pipeline/SBT + optixLaunch ---------------- */
@@ -155,6 +173,9 @@ int hjr_upload_scene(hjr_ctx*, const hjr_scene_view*);
 int hjr_set_transforms(hjr_ctx*, const float* transforms12, const float* inv_transforms12, uint32_t n_instances);
 /* setLUT — renderer.h:854-898 (uchar4, normalised float read, linear, wrap).  NULL clears. */
 int hjr_set_lut(hjr_ctx*, const uint8_t* rgba, int w, int h);
+/* setSky — renderer.h:802-851: equirect float4 IBL texture (wrap, linear, element read).  NULL restores the 1x1 texel
+ * `hjr_params.sky` (scene_sky_default).  Direction -> (u, v): u = atan2(d.z, d.x) / 2pi + 0.5, v = acos(d.y) / pi (build-defined). */
+int hjr_set_sky(hjr_ctx*, const float* rgba32f, int w, int h);
 /* Params fill + optixLaunch + CUDA_SYNC_CHECK + AOV D->H — renderer.h:1175-1242, 103-136.
  * Host buffers, width*height*4 floats each (albedo/normal may be NULL).  Synchronous. */
 int hjr_render(hjr_ctx*, const hjr_params*, float* aov_color, float* aov_albedo, float* aov_normal);

@@ -145,6 +145,26 @@ float hjo_p_pow(float x, float y)
     return p_exp(t);
 }
 float hjo_p_pow5(float x) { float x2 = x * x; float x4 = x2 * x2; return x4 * x; }
+/* Cephes atanf on [0, inf) + quadrant logic; x == y == 0 -> 0 */
+static inline float p_atan_pos(float x)
+{
+    float y0;
+    if (x > 2.414213562373095f) { y0 = 1.57079632679489661923f; x = -(1.0f / x); }
+    else if (x > 0.4142135623730950f) { y0 = 0.78539816339744830962f; x = (x - 1.0f) / (x + 1.0f); }
+    else y0 = 0.0f;
+    float z = x * x;
+    float p = fmaf(fmaf(fmaf(8.05374449538e-2f, z, -1.38776856032e-1f), z, 1.99777106478e-1f), z, -3.33329491539e-1f);
+    return y0 + fmaf(p * z, x, x);
+}
+float hjo_p_atan2(float y, float x)
+{
+    if (x != x || y != y) return x + y;
+    if (y == 0.0f) return (x >= 0.0f && !(f2bits(x) >> 31)) ? y : copysignf(HJ_PI, y);
+    if (x == 0.0f) return copysignf(1.57079632679489661923f, y);
+    float a = p_atan_pos(fabsf(y / x));
+    if (x < 0.0f) a = HJ_PI - a;
+    return copysignf(a, y);
+}
 
 /* math back-end dispatch.
  * mode 0 (LIBM)      : the reference's un-suffixed sin/cos/acos/pow/sqrt/fma calls bind to the FLOAT overloads,
@@ -368,6 +388,59 @@ void hjo_lut_fetch(const uint8_t* rgba, int w, int h, float u, float v, float* o
         float t11 = (float)rgba[4 * (j1 * w + i1) + c] * (1.0f / 255.0f);
         out[c] = (1.0f - ax) * (1.0f - ay) * t00 + ax * (1.0f - ay) * t10 + (1.0f - ax) * ay * t01 + ax * ay * t11;
     }
+}
+
+/* ------------------------------------------------------------------ material textures (renderer.h:740-800) and the equirect sky
+ * (renderer.h:802-851).  Sampling in the closest-hit / miss programs is build-defined (their source is missing):
+ * 8-bit RGBA, wrap, bilinear with the CUDA 1.8 fixed-point weights, sRGB -> linear per texel BEFORE filtering when the texture
+ * is TexType::sRGB; sky: float texels, same filter, direction -> (u, v) = (atan2(d.z, d.x) / 2pi + 0.5, acos(d.y) / pi). */
+static float g_srgb_lut[256];
+static int g_srgb_ready = 0;
+static void srgb_init(void)
+{
+    if (g_srgb_ready) return;
+    for (int i = 0; i < 256; i++) {
+        double c = (double)i / 255.0;
+        g_srgb_lut[i] = (float)(c <= 0.04045 ? c / 12.92 : pow((c + 0.055) / 1.055, 2.4));
+    }
+    g_srgb_ready = 1;
+}
+void hjo_tex_fetch(const uint8_t* rgba, int w, int h, int srgb, float u, float v, float* out)
+{
+    if (!rgba || w <= 0 || h <= 0) { out[0] = out[1] = out[2] = 0.0f; return; }
+    srgb_init();
+    float x = u * (float)w - 0.5f, y = v * (float)h - 0.5f;
+    float fx = floorf(x), fy = floorf(y);
+    float ax = floorf((x - fx) * 256.0f + 0.5f) * (1.0f / 256.0f);
+    float ay = floorf((y - fy) * 256.0f + 0.5f) * (1.0f / 256.0f);
+    int i0 = (int)fx % w; if (i0 < 0) i0 += w;
+    int j0 = (int)fy % h; if (j0 < 0) j0 += h;
+    int i1 = (i0 + 1) % w, j1 = (j0 + 1) % h;
+    float w00 = (1.0f - ax) * (1.0f - ay), w10 = ax * (1.0f - ay), w01 = (1.0f - ax) * ay, w11 = ax * ay;
+    for (int c = 0; c < 3; c++) {
+        uint8_t b00 = rgba[4 * (j0 * w + i0) + c], b10 = rgba[4 * (j0 * w + i1) + c], b01 = rgba[4 * (j1 * w + i0) + c], b11 = rgba[4 * (j1 * w + i1) + c];
+        float t00, t10, t01, t11;
+        if (srgb) { t00 = g_srgb_lut[b00]; t10 = g_srgb_lut[b10]; t01 = g_srgb_lut[b01]; t11 = g_srgb_lut[b11]; }
+        else { const float k = 1.0f / 255.0f; t00 = (float)b00 * k; t10 = (float)b10 * k; t01 = (float)b01 * k; t11 = (float)b11 * k; }
+        out[c] = w00 * t00 + w10 * t10 + w01 * t01 + w11 * t11;
+    }
+}
+static inline float m_atan2(int mode, float y, float x) { return mode == 1 ? hjo_p_atan2(y, x) : atan2f(y, x); }
+static inline float m_acos1(int mode, float x) { return mode == 1 ? hjo_p_acos(x) : acosf(x); }
+void hjo_sky_fetch(int mm, const float* rgba, int w, int h, const float* d, float* out)
+{
+    float u = m_atan2(mm, d[2], d[0]) * 0.15915494309189533577f + 0.5f;
+    float v = m_acos1(mm, clampf(d[1], -1.0f, 1.0f)) * HJ_INV_PI;
+    float x = u * (float)w - 0.5f, y = v * (float)h - 0.5f;
+    float fx = floorf(x), fy = floorf(y);
+    float ax = floorf((x - fx) * 256.0f + 0.5f) * (1.0f / 256.0f);
+    float ay = floorf((y - fy) * 256.0f + 0.5f) * (1.0f / 256.0f);
+    int i0 = (int)fx % w; if (i0 < 0) i0 += w;
+    int j0 = (int)fy % h; if (j0 < 0) j0 += h;
+    int i1 = (i0 + 1) % w, j1 = (j0 + 1) % h;
+    float w00 = (1.0f - ax) * (1.0f - ay), w10 = ax * (1.0f - ay), w01 = (1.0f - ax) * ay, w11 = ax * ay;
+    for (int c = 0; c < 3; c++)
+        out[c] = w00 * rgba[4 * (j0 * w + i0) + c] + w10 * rgba[4 * (j0 * w + i1) + c] + w01 * rgba[4 * (j1 * w + i0) + c] + w11 * rgba[4 * (j1 * w + i1) + c];
 }
 
 /* ------------------------------------------------------------------ DisneyBRDF (disneyBRDF.h:16-327) */
@@ -980,7 +1053,11 @@ static void RayTrace(tctx* T, f3 o, f3 d, float tmin, float tmax, payload* prd)
     T->st.closest_rays++; T->st.box_tests_closest += ts.box; T->st.tri_tests_closest += ts.tri;
     if (prim < 0) { /* miss: constant sky (renderer.h:802-851 with use_IBL=false) */
         prd->is_hit = 0;
-        prd->emission = muls(V(T->P->sky[0], T->P->sky[1], T->P->sky[2]), T->P->ibl_intensity);
+        if (c->sc.sky_rgba && c->sc.sky_w > 0 && c->sc.sky_h > 0) { /* tex2D(ibl_texture, u, v) * ibl_intensity */
+            float dir[3] = { d.x, d.y, d.z }, e[3];
+            hjo_sky_fetch(c->mm, c->sc.sky_rgba, c->sc.sky_w, c->sc.sky_h, dir, e);
+            prd->emission = muls(V(e[0], e[1], e[2]), T->P->ibl_intensity);
+        } else prd->emission = muls(V(T->P->sky[0], T->P->sky[1], T->P->sky[2]), T->P->ibl_intensity);
         return;
     }
     const wtri* W = &c->tri[prim]; const wshade* S = &c->shade[prim];
@@ -991,6 +1068,20 @@ static void RayTrace(tctx* T, f3 o, f3 d, float tmin, float tmax, payload* prd)
     prd->texcoord.x = S->t0.x * w0 + S->t1.x * b1 + S->t2.x * b2;
     prd->texcoord.y = S->t0.y * w0 + S->t1.y * b1 + S->t2.y * b2;
     payload_from_material(prd, &c->sc.materials[S->mat]);
+    { /* material textures: factor x texel (glTF 2.0 semantics; build-defined, the closest-hit source is missing) */
+        const hjo_material* m = &c->sc.materials[S->mat];
+        if (m->basecolor_tex >= 0 && (uint32_t)m->basecolor_tex < c->sc.n_textures) {
+            const hjo_texture* tx = &c->sc.textures[m->basecolor_tex];
+            float e[3]; hjo_tex_fetch(tx->rgba8, (int)tx->width, (int)tx->height, tx->srgb, prd->texcoord.x, prd->texcoord.y, e);
+            prd->basecolor = mul(prd->basecolor, V(e[0], e[1], e[2]));
+        }
+        if (m->metallic_roughness_tex >= 0 && (uint32_t)m->metallic_roughness_tex < c->sc.n_textures) {
+            const hjo_texture* tx = &c->sc.textures[m->metallic_roughness_tex];
+            float e[3]; hjo_tex_fetch(tx->rgba8, (int)tx->width, (int)tx->height, tx->srgb, prd->texcoord.x, prd->texcoord.y, e);
+            prd->roughness = prd->roughness * e[1];
+            prd->metallic = prd->metallic * e[2];
+        }
+    }
     prd->primitive_id = prim; prd->instance_id = (int)S->inst;
     T->st.shaded_hits++;
 }

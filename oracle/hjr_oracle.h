@@ -47,8 +47,12 @@ typedef struct hjo_material {
     int32_t is_light;
     int32_t ideal_specular;
     int32_t is_thinfilm;
-    int32_t _pad;
-} hjo_material; /* 64 bytes */
+    int32_t basecolor_tex;          /* texture slot or -1 */
+    int32_t metallic_roughness_tex; /* slot or -1: G = roughness, B = metallic */
+    int32_t normal_tex, emission_tex, _reserved;
+} hjo_material; /* 80 bytes */
+
+typedef struct hjo_texture { const uint8_t* rgba8; uint32_t width, height; int32_t srgb; int32_t _reserved; } hjo_texture;
 
 /* Mirror of SceneData (scene.h:19-36) + the per-frame Matrix4x3 arrays (renderer.h:257-291). */
 typedef struct hjo_scene {
@@ -66,6 +70,10 @@ typedef struct hjo_scene {
     const float*    light_prim_emission; /* 3*n_lights */
     const uint8_t*  lut_rgba;      /* thin-film LUT, may be NULL */
     int32_t lut_w, lut_h;
+    const hjo_texture* textures;   /* material texture slots */
+    uint32_t n_textures;
+    int32_t sky_w, sky_h;          /* equirect IBL (float RGBA), 0 = constant sky from hjo_params.sky */
+    const float*    sky_rgba;
 } hjo_scene;
 
 typedef struct hjo_params {
@@ -119,7 +127,11 @@ void     hjo_bsdf_eval(int math_mode, const hjo_material* mat, const float* wo3,
 float    hjo_bsdf_pdf(int math_mode, const hjo_material* mat, const float* wo3, const float* wi3);
 /* portable math, for ulp comparisons against libm */
 float hjo_p_sin(float x); float hjo_p_cos(float x); float hjo_p_acos(float x);
-float hjo_p_pow(float x, float y); float hjo_p_pow5(float x);
+float hjo_p_pow(float x, float y); float hjo_p_pow5(float x); float hjo_p_atan2(float y, float x);
+/* 8-bit RGBA texture fetch: wrap, bilinear (CUDA weights), optional sRGB decode before filtering */
+void hjo_tex_fetch(const uint8_t* rgba, int w, int h, int srgb, float u, float v, float* out3);
+/* equirect sky lookup for a unit direction */
+void hjo_sky_fetch(int math_mode, const float* rgba, int w, int h, const float* dir3, float* out3);
 /* thin-film LUT lookup (disneyBRDF.h:11-14 + renderer.h:854-898 sampler state) */
 void hjo_lut_fetch(const uint8_t* rgba, int w, int h, float u, float v, float* out3);
 /* output stage (renderer.h:73-101) */

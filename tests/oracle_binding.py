@@ -22,14 +22,27 @@ class Material(C.Structure):
     _fields_ = [("basecolor", C.c_float * 3), ("metallic", C.c_float), ("roughness", C.c_float),
                 ("sheen", C.c_float), ("clearcoat", C.c_float), ("ior", C.c_float),
                 ("transmission", C.c_float), ("emission", C.c_float * 3), ("is_light", C.c_int32),
-                ("ideal_specular", C.c_int32), ("is_thinfilm", C.c_int32), ("_pad", C.c_int32)]
+                ("ideal_specular", C.c_int32), ("is_thinfilm", C.c_int32), ("basecolor_tex", C.c_int32),
+                ("metallic_roughness_tex", C.c_int32), ("normal_tex", C.c_int32), ("emission_tex", C.c_int32),
+                ("_reserved", C.c_int32)]
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.basecolor_tex = self.metallic_roughness_tex = self.normal_tex = self.emission_tex = -1
 
 
 MATERIAL_DTYPE = np.dtype([("basecolor", "<f4", 3), ("metallic", "<f4"), ("roughness", "<f4"),
                            ("sheen", "<f4"), ("clearcoat", "<f4"), ("ior", "<f4"),
                            ("transmission", "<f4"), ("emission", "<f4", 3), ("is_light", "<i4"),
-                           ("ideal_specular", "<i4"), ("is_thinfilm", "<i4"), ("_pad", "<i4")])
-assert MATERIAL_DTYPE.itemsize == 64 and C.sizeof(Material) == 64
+                           ("ideal_specular", "<i4"), ("is_thinfilm", "<i4"), ("basecolor_tex", "<i4"),
+                           ("metallic_roughness_tex", "<i4"), ("normal_tex", "<i4"), ("emission_tex", "<i4"),
+                           ("_reserved", "<i4")])
+assert MATERIAL_DTYPE.itemsize == 80 and C.sizeof(Material) == 80
+
+
+class Texture(C.Structure):
+    _fields_ = [("rgba8", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32), ("srgb", C.c_int32),
+                ("_reserved", C.c_int32)]
 
 
 class Scene(C.Structure):
@@ -39,7 +52,8 @@ class Scene(C.Structure):
                 ("prim_offsets", C.c_void_p), ("transforms", C.c_void_p), ("inv_transforms", C.c_void_p),
                 ("materials", C.c_void_p), ("light_prim_ids", C.c_void_p),
                 ("light_prim_emission", C.c_void_p), ("lut_rgba", C.c_void_p),
-                ("lut_w", C.c_int32), ("lut_h", C.c_int32)]
+                ("lut_w", C.c_int32), ("lut_h", C.c_int32), ("textures", C.c_void_p), ("n_textures", C.c_uint32),
+                ("sky_w", C.c_int32), ("sky_h", C.c_int32), ("sky_rgba", C.c_void_p)]
 
 
 class Params(C.Structure):
@@ -92,6 +106,10 @@ def lib():
                                     C.c_void_p]
         L.hjo_bsdf_pdf.restype = C.c_float
         L.hjo_bsdf_pdf.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.hjo_p_atan2.restype = C.c_float
+        L.hjo_p_atan2.argtypes = [C.c_float, C.c_float]
+        L.hjo_tex_fetch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]
+        L.hjo_sky_fetch.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         for n in ("hjo_p_sin", "hjo_p_cos", "hjo_p_acos", "hjo_p_pow5"):
             getattr(L, n).restype = C.c_float
             getattr(L, n).argtypes = [C.c_float]
@@ -148,6 +166,21 @@ class OracleScene:
         if a["lut_rgba"] is not None:
             s.lut_rgba = a["lut_rgba"].ctypes.data
             s.lut_h, s.lut_w = a["lut_rgba"].shape[:2]
+        texs = arrays.get("textures") or []
+        if texs:
+            a["tex_px"] = [np.ascontiguousarray(t[0], dtype=np.uint8) for t in texs]
+            self._texarr = (Texture * len(texs))()
+            for i, (t, px) in enumerate(zip(texs, a["tex_px"])):
+                self._texarr[i].rgba8 = px.ctypes.data
+                self._texarr[i].height, self._texarr[i].width = px.shape[0], px.shape[1]
+                self._texarr[i].srgb = int(t[1])
+            s.textures = C.addressof(self._texarr)
+            s.n_textures = len(texs)
+        sky = arrays.get("sky_rgba")
+        if sky is not None:
+            a["sky_rgba"] = np.ascontiguousarray(sky, dtype=np.float32)
+            s.sky_rgba = a["sky_rgba"].ctypes.data
+            s.sky_h, s.sky_w = a["sky_rgba"].shape[:2]
         self.scene = s
         self.math_mode = math_mode
         self.ctx = lib().hjo_create(C.byref(s), math_mode)

@@ -28,11 +28,11 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_struct_layouts_match_header():
-    assert C.sizeof(hjr.Material) == 64 and hjr.MATERIAL_DTYPE.itemsize == 64
+    assert C.sizeof(hjr.Material) == 80 and hjr.MATERIAL_DTYPE.itemsize == 80 and C.sizeof(hjr.Texture) == 24
     assert C.sizeof(hjr.Camera) == 52
     assert C.sizeof(hjr.Params) == 6 * 4 + 52 + 12 + 4 + 16
     assert C.sizeof(hjr.Stats) == 10 * 8 + 16
-    assert C.sizeof(hjr.SceneView) == 6 * 4 + 12 * 8
+    assert C.sizeof(hjr.SceneView) == 8 * 4 + 13 * 8
 
 
 def test_no_silent_fallback_without_gpu():

@@ -71,3 +71,33 @@ def test_stress_scene_100k(tmp_path):
     s = StressScene(tmp_path, spheres=16, segments=128)
     assert s.scene.view.n_triangles > 250000
     check(s, 48, 27, 2)
+
+
+def test_textured_scene():
+    """cornelbox_texture_test.gltf (base-colour PNG texture, sRGB) — §8 row f2."""
+    s = Cornell("render_option_tex.json")
+    assert s.scene.view.n_textures == 1
+    color, _ = check(s, 128, 96, 8)
+    assert np.isfinite(color).all()
+
+
+def test_equirect_sky(tmp_path):
+    """IBL through the miss program: generated equirect HDR, uploaded with hjr_set_sky, against the oracle."""
+    rng = np.random.default_rng(3)
+    sky = np.zeros((32, 64, 4), np.float32)
+    sky[..., :3] = rng.uniform(0.0, 3.0, (32, 64, 3)).astype(np.float32)
+    s = Cornell()
+    d = s.device()
+    try:
+        d.set_sky(sky)
+        p = s.hjr_params(96, 64, 6, ibl_intensity=0.7)
+        color, albedo, normal = d.render(p)
+        d.set_sky(None)
+        plain, _, _ = d.render(p)
+    finally:
+        d.close()
+    arrays = dict(s.arrays, sky_rgba=sky)
+    oc, oa, on, st = ob.OracleScene(arrays, ob.MATH_PORTABLE).render(s.oracle_params(96, 64, 6, ibl_intensity=0.7))
+    assert_bitexact(color, oc, "aov_color")
+    assert_bitexact(normal, on, "aov_normal")
+    assert not np.array_equal(color, plain)

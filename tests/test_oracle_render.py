@@ -92,6 +92,8 @@ def test_white_furnace():
     mats[0]["metallic"] = 1.0
     mats[0]["roughness"] = 0.7
     mats[0]["ior"] = 1.0
+    for k in ("basecolor_tex", "metallic_roughness_tex", "normal_tex", "emission_tex"):
+        mats[0][k] = -1
     arrays = dict(vertices=v, normals=nrm, texcoords=np.zeros((6, 2), np.float32), indices=np.arange(6, dtype=np.uint32),
                   material_ids=np.zeros(2, np.uint32), prim_offsets=np.zeros(1, np.uint32),
                   transforms=np.array([[1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0]], np.float32),

@@ -134,6 +134,7 @@ def lib():
             "hjr_synchronize": [C.c_void_p],
             "hjr_get_stats": [C.c_void_p, C.c_void_p],
             "hjr_float4_to_srgb8": [C.c_void_p, C.c_void_p, C.c_uint32],
+            "hjr_tonemap_to_srgb8": [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int],
             "hjr_write_png": [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int],
             "hjr_write_pfm": [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32],
             "hjr_render_file": [C.c_char_p, C.c_int],
@@ -198,6 +199,17 @@ def float4_to_srgb8(rgba):
     a = np.ascontiguousarray(rgba, dtype=np.float32)
     out = np.zeros(a.shape, dtype=np.uint8)
     _check(lib().hjr_float4_to_srgb8(a.ctypes.data, out.ctypes.data, a.size // 4), "hjr_float4_to_srgb8")
+    return out
+
+
+TONEMAP_NONE, TONEMAP_UCHIMURA, TONEMAP_ACES = 0, 1, 2
+
+
+def tonemap_to_srgb8(rgba, tonemap):
+    """kernel/color.h tonemapper, then toSRGB + quantise (renderer.h:73-101)."""
+    a = np.ascontiguousarray(rgba, dtype=np.float32)
+    out = np.zeros(a.shape, dtype=np.uint8)
+    _check(lib().hjr_tonemap_to_srgb8(a.ctypes.data, out.ctypes.data, a.size // 4, tonemap), "hjr_tonemap_to_srgb8")
     return out
 
 

@@ -17,6 +17,7 @@ bool read_png_rgba8(const std::string& path, std::vector<uint8_t>& rgba, int& w,
 bool write_pfm(const std::string& path, const float* rgba, uint32_t w, uint32_t h, std::string& err);
 bool read_hdr_rgba32f(const std::string& path, std::vector<float>& rgba, int& w, int& h, std::string& err);
 void float4_to_srgb8(const float* rgba, uint8_t* out, uint32_t n);
+void tonemap_to_srgb8(const float* rgba, uint8_t* out, uint32_t n, int mode);
 } // namespace hjr
 using hjr::set_error;
 
@@ -132,6 +133,14 @@ extern "C" int hjr_float4_to_srgb8(const float* rgba, uint8_t* out, uint32_t n)
 {
     if ((!rgba || !out) && n) { set_error("hjr_float4_to_srgb8: null argument"); return HJR_ERR_ARG; }
     hjr::float4_to_srgb8(rgba, out, n);
+    return HJR_OK;
+}
+
+extern "C" int hjr_tonemap_to_srgb8(const float* rgba, uint8_t* out, uint32_t n, int tonemap)
+{
+    if ((!rgba || !out) && n) { set_error("hjr_tonemap_to_srgb8: null argument"); return HJR_ERR_ARG; }
+    if (tonemap < HJR_TONEMAP_NONE || tonemap > HJR_TONEMAP_ACES) { set_error("hjr_tonemap_to_srgb8: unknown tonemap"); return HJR_ERR_ARG; }
+    hjr::tonemap_to_srgb8(rgba, out, n, tonemap);
     return HJR_OK;
 }
 

@@ -251,4 +251,43 @@ void float4_to_srgb8(const float* rgba, uint8_t* out, uint32_t n)
     }
 }
 
+
+/* kernel/color.h:10-29.  The double literals (1.0, 0.0) promote the surrounding sub-expressions exactly as written there. */
+static float tonemap_uchimura1(float x, float P, float a, float m, float l, float c, float b)
+{
+    float l0 = ((P - m) * l) / a;
+    float S0 = m + l0;
+    float S1 = m + a * l0;
+    float C2 = (a * P) / (P - S1);
+    float CP = -C2 / P;
+    /* smoothstep(0.0, m, x) (math.h:113-116), step(m + l0, x) (math.h:118-120) */
+    float sx = fmaxf(0.0f, fminf((x - 0.0f) / (m - 0.0f), 1.0f));
+    float w0 = (float)(1.0 - (double)(sx * sx * (3.0f - 2.0f * sx)));
+    float w2 = (float)((m + l0) < x);
+    float w1 = (float)(1.0 - (double)w0 - (double)w2);
+    float T = (float)((double)m * pow((double)(x / m), (double)c) + (double)b);
+    float S = (float)((double)P - (double)(P - S1) * exp((double)(CP * (x - S0))));
+    float L = m + a * (x - m);
+    return T * w0 + L * w1 + S * w2;
+}
+static float tonemap_uchimura(float x) { return tonemap_uchimura1(x, 1.0f, 1.0f, 0.22f, 0.4f, 1.33f, 0.0f); } /* color.h:31-39 */
+static float tonemap_aces(float x) /* color.h:55-63 */
+{
+    const float a = 2.51f, b = 0.03f, c = 2.43f, d = 0.59f, e = 0.14f;
+    return fmaxf(0.0f, fminf((x * (a * x + b)) / (x * (c * x + d) + e), 1.0f));
+}
+
+void tonemap_to_srgb8(const float* rgba, uint8_t* out, uint32_t n, int mode)
+{
+    float px[4];
+    for (uint32_t i = 0; i < n; i++) {
+        for (int c = 0; c < 3; c++) {
+            float v = rgba[4 * (size_t)i + c];
+            px[c] = mode == 1 ? tonemap_uchimura(v) : (mode == 2 ? tonemap_aces(v) : v);
+        }
+        px[3] = 1.0f;
+        float4_to_srgb8(px, out + 4 * (size_t)i, 1);
+    }
+}
+
 } // namespace hjr

@@ -189,6 +189,10 @@ int hjr_get_stats(hjr_ctx*, hjr_stats* out);
 /* ---------------- output stage (host) ---------------- */
 /* float4ConvertColor: toSRGB + quantizeUnsignedChar — renderer/renderer.h:73-101 */
 int hjr_float4_to_srgb8(const float* rgba, uint8_t* out_rgba8, uint32_t n_pixels);
+/* Preview-buffer tonemappers of kernel/color.h: HJR_TONEMAP_UCHIMURA (color.h:10-53), HJR_TONEMAP_ACES (color.h:55-63),
+ * applied per channel before the sRGB + quantise stage above (the raygen code that used them is missing: build-defined order). */
+enum { HJR_TONEMAP_NONE = 0, HJR_TONEMAP_UCHIMURA = 1, HJR_TONEMAP_ACES = 2 };
+int hjr_tonemap_to_srgb8(const float* rgba, uint8_t* out_rgba8, uint32_t n_pixels, int tonemap);
 /* sutil::saveImage(name, buffer, false) — renderer.h:1291-1302.  flip_y != 0 writes row 0 at the bottom. */
 int hjr_write_png(const char* path, const uint8_t* rgba8, uint32_t width, uint32_t height, int flip_y);
 int hjr_write_pfm(const char* path, const float* rgba, uint32_t width, uint32_t height);

@@ -136,6 +136,9 @@ void hjo_sky_fetch(int math_mode, const float* rgba, int w, int h, const float* 
 void hjo_lut_fetch(const uint8_t* rgba, int w, int h, float u, float v, float* out3);
 /* output stage (renderer.h:73-101) */
 void hjo_float4_to_srgb8(const float* rgba, uint8_t* out, uint32_t n_pixels);
+/* kernel/color.h tonemappers (1 = Uchimura :10-53, 2 = ACES :55-63) followed by the stage above */
+void hjo_tonemap_to_srgb8(const float* rgba, uint8_t* out, uint32_t n_pixels, int mode);
+float hjo_tonemap(float x, int mode);
 
 #ifdef __cplusplus
 }

@@ -117,6 +117,9 @@ def lib():
         L.hjo_p_pow.argtypes = [C.c_float, C.c_float]
         L.hjo_lut_fetch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]
         L.hjo_float4_to_srgb8.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+        L.hjo_tonemap_to_srgb8.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]
+        L.hjo_tonemap.restype = C.c_float
+        L.hjo_tonemap.argtypes = [C.c_float, C.c_int]
         L.hjo_create.restype = C.c_void_p
         L.hjo_create.argtypes = [C.c_void_p, C.c_int]
         L.hjo_destroy.argtypes = [C.c_void_p]

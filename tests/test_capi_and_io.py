@@ -107,3 +107,33 @@ def test_tile_ownership_partitions_the_frame():
         counts = [int(hjr.owned_tile_mask(w, h, r, R).sum()) for r in range(R)]
         if w * h > 4096:
             assert max(counts) - min(counts) <= 64 * 2 + (w % 8 + h % 8) * max(w, h)
+
+
+def test_tonemappers_match_oracle_and_formulae():
+    """kernel/color.h: Uchimura (:10-53) and ACES (:55-63) on the preview buffer, then the sRGB stage."""
+    L = ob.lib()
+    xs = np.concatenate([np.linspace(0, 4, 400), [0.22, 0.62, 1e-6, 100.0]]).astype(np.float32)
+    px = np.zeros((len(xs), 4), np.float32)
+    px[:, 0] = xs
+    px[:, 1] = xs * 0.5
+    px[:, 2] = xs[::-1]
+    px[:, 3] = 1
+    for mode in (hjr.TONEMAP_NONE, hjr.TONEMAP_UCHIMURA, hjr.TONEMAP_ACES):
+        a = hjr.tonemap_to_srgb8(px, mode)
+        b = np.zeros_like(a)
+        L.hjo_tonemap_to_srgb8(px.ctypes.data, b.ctypes.data, len(xs), mode)
+        assert np.array_equal(a, b)
+    assert np.array_equal(hjr.tonemap_to_srgb8(px, hjr.TONEMAP_NONE), hjr.float4_to_srgb8(px))
+
+    def aces(x):
+        return np.clip((x * (2.51 * x + 0.03)) / (x * (2.43 * x + 0.59) + 0.14), 0, 1)
+    for x in (0.0, 0.18, 1.0, 3.0):
+        assert abs(L.hjo_tonemap(x, 2) - aces(x)) < 1e-6
+    # Uchimura with P=1,a=1,m=0.22,l=0.4: toe below m, linear up to m+l0, shoulder towards P
+    assert abs(L.hjo_tonemap(0.0, 1)) < 1e-7
+    assert abs(L.hjo_tonemap(0.5, 1) - 0.5) < 1e-6          # linear section [0.22, 0.532]... and blend weights sum to 1
+    assert 0.9 < L.hjo_tonemap(2.0, 1) < 1.0 and L.hjo_tonemap(50.0, 1) <= 1.0
+    ys = np.array([L.hjo_tonemap(float(x), 1) for x in np.linspace(0, 5, 200)])
+    assert np.all(np.diff(ys) >= -1e-6)
+    with pytest.raises(hjr.HjrError):
+        hjr.tonemap_to_srgb8(px, 7)

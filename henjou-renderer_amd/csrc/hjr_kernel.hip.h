@@ -610,7 +610,7 @@ HD uint32_t node_step(const float4* nodes, uint32_t& cur, const BoxRay& R, float
     t0 = fmaf(q2.x, inv.z, oi.z); t1 = fmaf(q2.w, inv.z, oi.z);
     lo1 = fmaxf(lo1, fminf(t0, t1)); hi1 = fminf(hi1, fmaxf(t0, t1));
     lo1 = fmaxf(lo1, tmin); hi1 = fminf(hi1, tfar);
-    const bool h0 = lo0 <= hi0 * 1.0000004f, h1 = lo1 <= hi1 * 1.0000004f;
+    const bool h0 = lo0 <= hi0, h1 = lo1 <= hi1; // conservative through the 2^-15 box padding (>= 16x the rounding error of t)
     const uint32_t c0 = f2bits(q3.x), c1 = f2bits(q3.y);
     if (h0 && h1) {
         const bool swap = lo1 < lo0;

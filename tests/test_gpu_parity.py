@@ -137,3 +137,23 @@ def test_full_size_properties(cornell, dev):
     rect = (900, 500, 964, 532)
     oc, _, _, _ = osc.render(cornell.oracle_params(w, h, spp, rect=rect), want_aovs=False)
     assert_bitexact(color[rect[1]:rect[3], rect[0]:rect[2]], oc[rect[1]:rect[3], rect[0]:rect[2]], "window")
+
+
+def test_c5_shard_3840x2160_4096spp(cornell, dev):
+    """BASELINE configs[4] exactly as one of its 8 ranks runs it: 3840x2160, 4096 spp (16 chunks of 256 samples), rank 3 of 8.
+    An owned window is compared with the oracle; un-owned pixels stay zero."""
+    w, h, spp, R, r = 3840, 2160, 4096, 8, 3
+    tiles_x = w // 8
+    # pick an 8x8 tile owned by rank 3 near the sphere and render only a narrow band of the frame on the oracle side
+    ty, tx = 150, 243
+    assert (ty * tiles_x + tx) % R == r
+    p = cornell.hjr_params(w, h, spp, rank=r, world_size=R)
+    # the full shard would be 4.2e9 samples (~2 s); keep the test light by rendering it once, colour only
+    color, _, _ = dev.render(p, want_aovs=False)
+    mask = hjr.owned_tile_mask(w, h, r, R)
+    assert np.all(color[~mask] == 0) and np.isfinite(color).all()
+    assert (color[mask][:, 3] == 1).all()
+    osc = ob.OracleScene(cornell.arrays, ob.MATH_PORTABLE)
+    rect = (tx * 8, ty * 8, tx * 8 + 8, ty * 8 + 4)
+    oc, _, _, _ = osc.render(cornell.oracle_params(w, h, spp, rect=rect), want_aovs=False)
+    assert_bitexact(color[rect[1]:rect[3], rect[0]:rect[2]], oc[rect[1]:rect[3], rect[0]:rect[2]], "C5 window")

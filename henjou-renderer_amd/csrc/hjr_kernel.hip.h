@@ -945,6 +945,7 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
 #ifdef HJR_TIMING
     // diagnostic build: wave-clock shares of the loop's phases, summed per wave into P.stats[10..15] (never in the shipped build)
     unsigned long long tk[6] = { 0, 0, 0, 0, 0, 0 }, tk6 = 0, tk7 = 0;
+    unsigned long long oc[6] = { 0, 0, 0, 0, 0, 0 }; // wave iterations, lanes tracing closest, lanes with a shadow ray, lanes shading, msGGX lanes, glass lanes
     unsigned long long tstamp = __builtin_amdgcn_s_memtime();
 #define HJR_TICK(i) { __builtin_amdgcn_sched_barrier(0); unsigned long long now_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); tk[i] += now_ - tstamp; tstamp = now_; }
 #else
@@ -1031,6 +1032,9 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
         }
 
         HJR_TICK(0)
+#ifdef HJR_TIMING
+        oc[0] += 1; oc[1] += __popcll(__ballot(tracing)); oc[2] += __popcll(__ballot(sh_valid));
+#endif
         // ---- one fused traversal: pending shadow ray (TraceOcculution, rt.h:236-243) then closest-hit ray (RayTrace, rt.h:182-189)
         bool occluded = false;
         Hit h;
@@ -1071,6 +1075,9 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
                 if (write_pending) write_out();
             } else {
                 HJR_TICK(2)
+#ifdef HJR_TIMING
+                oc[3] += __popcll(__ballot(true)); oc[4] += __popcll(__ballot(!prd.surf.is_specular && prd.surf.metallic > 0.5f)); oc[5] += __popcll(__ballot(prd.surf.is_specular));
+#endif
                 CMJState st = path_rng(P, px, py, s, ps.rng_depth);
                 const Surface& sf = prd.surf;
                 f3 t, b;
@@ -1182,6 +1189,7 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
     }
 #ifdef HJR_TIMING
     if (lane == 0) { for (int i = 0; i < 6; i++) atomicAdd(&P.stats[HJR_NSTAT + i], tk[i]); atomicAdd(&P.stats[HJR_NSTAT + 6], tk6); atomicAdd(&P.stats[HJR_NSTAT + 7], tk7); }
+    if (__ffsll((long long)__ballot(true)) - 1 == (int)lane) for (int i = 0; i < 6; i++) atomicAdd(&P.stats[HJR_NSTAT + 8 + i], oc[i]);
 #endif
 
     if (STATS) {

@@ -1116,7 +1116,9 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
                         sh_contrib = ((ps.thr * ((bsdf * G * cosine1) / light_pdf)) * mis_weight) * light_color; // rt.h:378
                     }
                     sh_o = so; sh_d = sd; sh_tmax = light_distance - 0.001f;
-                    sh_valid = true;
+                    // an exactly-zero contribution (every hit on the glass lobe, whose evaluateBSDF is 0) cannot change L whatever
+                    // the shadow ray returns (x + 0 == x): skip the trace.  A NaN contribution still goes through.
+                    sh_valid = !(sh_contrib.x == 0.0f && sh_contrib.y == 0.0f && sh_contrib.z == 0.0f);
                 }
 
                 if (INTEGRATOR == HJR_INTEGRATOR_MIS_) { // BSDF-sampled light hit, rt.h:383-420

@@ -1179,14 +1179,18 @@ static f3 NEE(tctx* T, f3 o, f3 d, cmj_state state, f3* aov_albedo, f3* aov_norm
                 f3 sd = normalize(sub(light_position, so));
                 float light_distance = length3(sub(light_position, so));
                 float ipsiron_distance = 0.001f;
-                if (!TraceOcclusion(T, so, sd, 0.001f, light_distance - ipsiron_distance)) {
-                    float cosine1 = absdot(n, sd);
-                    float cosine2 = absdot(light_normal, neg(sd));
-                    f3 local_wi = world_to_local(sd, t, n, b);
-                    f3 bsdf = bsdf_eval(&bs, local_wo, local_wi);
-                    float G = cosine2 / (light_distance * light_distance);
-                    LTE = add(LTE, mul(mul(throughput, divs(muls(muls(bsdf, G), cosine1), light_pdf)), light_color));
-                }
+                /* The contribution does not depend on the shadow ray; an exactly-zero one (glass: evaluateBSDF == 0) cannot
+                 * change LTE (x + 0 == x), so its shadow ray is not traced (and not counted).  Same values as the reference's
+                 * trace-then-evaluate order, rt.h:236-259. */
+                float cosine1 = absdot(n, sd);
+                float cosine2 = absdot(light_normal, neg(sd));
+                f3 local_wi = world_to_local(sd, t, n, b);
+                f3 bsdf = bsdf_eval(&bs, local_wo, local_wi);
+                float G = cosine2 / (light_distance * light_distance);
+                f3 contrib = mul(mul(throughput, divs(muls(muls(bsdf, G), cosine1), light_pdf)), light_color);
+                if (!(contrib.x == 0.0f && contrib.y == 0.0f && contrib.z == 0.0f) &&
+                    !TraceOcclusion(T, so, sd, 0.001f, light_distance - ipsiron_distance))
+                    LTE = add(LTE, contrib);
             }
         }
         float pdf = 1.0f;
@@ -1254,16 +1258,17 @@ static f3 MIS(tctx* T, f3 o, f3 d, cmj_state* statep, f3* aov_albedo, f3* aov_no
                 f3 light_direction = sub(light_position, prd.position);
                 float light_distance = length3(light_direction);
                 light_direction = normalize(light_direction);
-                if (!TraceOcclusion(T, prd.position, light_direction, 0.001f, light_distance - 0.001f)) {
-                    float cosine1 = absdot(n, light_direction);
-                    float cosine2 = absdot(light_normal, neg(light_direction));
-                    f3 local_wi = world_to_local(light_direction, t, n, b);
-                    f3 bsdf = bsdf_eval(&bs, local_wo, local_wi);
-                    float G = cosine2 / (light_distance * light_distance);
-                    float pt_pdf = bsdf_pdf(&bs, local_wo, local_wi) * G;
-                    float mis_weight = light_pdf / (light_pdf + pt_pdf);
-                    LTE = add(LTE, mul(muls(mul(throughput, divs(muls(muls(bsdf, G), cosine1), light_pdf)), mis_weight), light_emission));
-                }
+                float cosine1 = absdot(n, light_direction);
+                float cosine2 = absdot(light_normal, neg(light_direction));
+                f3 local_wi = world_to_local(light_direction, t, n, b);
+                f3 bsdf = bsdf_eval(&bs, local_wo, local_wi);
+                float G = cosine2 / (light_distance * light_distance);
+                float pt_pdf = bsdf_pdf(&bs, local_wo, local_wi) * G;
+                float mis_weight = light_pdf / (light_pdf + pt_pdf);
+                f3 contrib = mul(muls(mul(throughput, divs(muls(muls(bsdf, G), cosine1), light_pdf)), mis_weight), light_emission);
+                if (!(contrib.x == 0.0f && contrib.y == 0.0f && contrib.z == 0.0f) &&
+                    !TraceOcclusion(T, prd.position, light_direction, 0.001f, light_distance - 0.001f))
+                    LTE = add(LTE, contrib);
             }
         }
         { /* Pathtrace */

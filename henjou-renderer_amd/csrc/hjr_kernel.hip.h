@@ -934,6 +934,7 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
     bool write_pending = false; // the item's last sample is finished; sums go out once fin_pending is resolved
     bool sh_valid = false;      // pending NEE shadow ray of the bounce shaded in the previous iteration
     uint32_t px = 0, py = 0, s = 0, s_end = 0, chunk = 0;
+    uint32_t w_next = 0, w_end = 0; // this wave's private item range (wave-uniform)
     f3 sumL = V1(0.0f), sumA = V1(0.0f), sumN = V1(0.0f);
     f3 sh_o = V1(0.0f), sh_d = V1(0.0f), sh_contrib = V1(0.0f), fin_L = V1(0.0f);
     float sh_tmax = 0.0f;
@@ -953,19 +954,25 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
 #endif
 
     for (;;) {
-        // ---- ray-queue refill: one wave-aggregated atomic hands out work items to every idle lane (ballot + mbcnt prefix)
+        // ---- ray-queue refill (ballot + mbcnt prefix): idle lanes take consecutive items from the wave's private range
+        //      [w_next, w_end); when it runs dry the wave fetches the next 64 items with ONE atomic on the global head.
         {
             const bool need = !has_item && !dead && !write_pending && !fin_pending && !sh_valid;
             const unsigned long long m = __ballot(need);
             if (m) {
                 const uint32_t n = (uint32_t)__popcll(m);
-                const uint32_t leader = (uint32_t)(__ffsll((long long)m) - 1);
-                uint32_t base = 0;
-                if (lane == leader) base = atomicAdd(P.queue_head, n);
-                base = (uint32_t)__shfl((int)base, (int)leader);
                 const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                uint32_t q = w_next + prefix;          // wave-uniform w_next / w_end
+                const uint32_t have = w_end - w_next;  // items left in the private range
+                if (n > have) {                        // not enough: lanes beyond `have` come from a fresh range
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(P.queue_head, 64u);
+                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                    if (prefix >= have) q = base + (prefix - have);
+                    w_next = base + (n - have);
+                    w_end = base + 64u;
+                } else w_next += n;
                 if (need) {
-                    const uint32_t q = base + prefix;
                     if (q < P.n_owned_items) {
                         // item q = ((owned tile * n_chunks) + chunk) * 64 + pixel-in-tile: the 64 lanes of a wave start on one
                         // tile and one sample chunk (coherent primary rays)

@@ -198,6 +198,7 @@ extern "C" int hjr_set_sky(hjr_ctx* c, const float* rgba, int w, int h)
 }
 
 template <int I, bool S, int W> static int launch_mem(const hjr_ctx* c, const KParams& kp, uint64_t n_items, hipStream_t st);
+template <int I, bool S, int W, bool A> static int launch_mem2(const hjr_ctx* c, const KParams& kp, uint64_t n_items, hipStream_t st);
 // lds_mode: 0 = BVH4 read from memory, 1 = BVH2 staged in LDS with 32-bit stack entries, 2 = with 16-bit entries, 3 = BVH2 from memory
 template <int I, bool S, bool S16, bool A> static int launch_lds2(const hjr_ctx* c, const KParams& kp, uint64_t n_items, hipStream_t st)
 {
@@ -225,8 +226,13 @@ template <int I, bool S> static int launch(const hjr_ctx* c, const KParams& kp, 
 }
 template <int I, bool S, int W> static int launch_mem(const hjr_ctx* c, const KParams& kp, uint64_t n_items, hipStream_t st)
 {
+    const bool full = kp.aov_albedo || kp.aov_normal || kp.tex_desc || kp.sky_tex;
+    return full ? launch_mem2<I, S, W, true>(c, kp, n_items, st) : launch_mem2<I, S, W, false>(c, kp, n_items, st);
+}
+template <int I, bool S, int W, bool A> static int launch_mem2(const hjr_ctx* c, const KParams& kp, uint64_t n_items, hipStream_t st)
+{
     const size_t smem = (size_t)HJR_BLOCK * kp.stack_depth * 4;
-    auto kern = hjr_render_kernel<I, S, HJR_BLOCK, false, false, W, true>;
+    auto kern = hjr_render_kernel<I, S, HJR_BLOCK, false, false, W, A>;
     int per_cu = 0;
     if (c->blocks_per_cu > 0) per_cu = c->blocks_per_cu;
     else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, HJR_BLOCK, smem) != hipSuccess || per_cu < 1)

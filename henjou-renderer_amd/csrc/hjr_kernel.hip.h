@@ -898,7 +898,7 @@ HD void start_path(const KParams& P, PathState& ps, uint32_t px, uint32_t py, ui
 }
 
 #ifndef HJR_MIN_WAVES
-#define HJR_MIN_WAVES 1
+#define HJR_MIN_WAVES 3 /* memory-path kernels: keep <= 168 VGPRs = 3 waves per SIMD (2 waves cost 20-30 %, profiles/r01_experiments.md) */
 #endif
 // Dynamic LDS: [traversal stacks: stack_depth x BLOCK uint32][nodes][tri_geom]  (the last two only when LDSBVH).
 // LDSBVH: the whole BVH + leaf-order triangles are staged into LDS once per persistent workgroup (coalesced dwordx4 loads),

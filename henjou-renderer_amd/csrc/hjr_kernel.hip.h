@@ -533,6 +533,23 @@ HD f3 crossf(f3 a, f3 b)
     return V(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
 }
 // canonical ray/triangle test — the same operation sequence as the oracle's ray_tri()
+#ifdef HJR_BRANCHLESS_TRI
+HD bool ray_tri(f3 v0, f3 v1, f3 v2, f3 o, f3 d, float tmin, float tmax, float& t, float& b1, float& b2)
+{
+    const f3 e1 = v1 - v0, e2 = v2 - v0;
+    const f3 p = crossf(d, e2);
+    const float det = dotf(e1, p);
+    const float inv = 1.0f / det;
+    const f3 tv = o - v0;
+    const float u = dotf(tv, p) * inv;
+    const f3 q = crossf(tv, e1);
+    const float v = dotf(d, q) * inv;
+    const float tt = dotf(e2, q) * inv;
+    const bool ok = (det != 0.0f) & (u >= 0.0f) & (u <= 1.0f) & (v >= 0.0f) & (u + v <= 1.0f) & (tt > tmin) & (tt < tmax);
+    t = tt; b1 = u; b2 = v;
+    return ok;
+}
+#else
 HD bool ray_tri(f3 v0, f3 v1, f3 v2, f3 o, f3 d, float tmin, float tmax, float& t, float& b1, float& b2)
 {
     f3 e1 = v1 - v0, e2 = v2 - v0;
@@ -551,6 +568,7 @@ HD bool ray_tri(f3 v0, f3 v1, f3 v2, f3 o, f3 d, float tmin, float tmax, float& 
     t = tt; b1 = u; b2 = v;
     return true;
 }
+#endif
 
 // ---- per-lane traversal stack in LDS, element i of this lane at stack[i * BLOCK] (conflict-free columns).  Small scenes that
 // are staged into LDS use 16-bit entries (node index < 32768, or leaf: bit15 | count << 13 | first triangle < 8192), which
@@ -612,6 +630,19 @@ HD uint32_t node_step(const float4* nodes, uint32_t& cur, const BoxRay& R, float
     lo1 = fmaxf(lo1, tmin); hi1 = fminf(hi1, tfar);
     const bool h0 = lo0 <= hi0, h1 = lo1 <= hi1; // conservative through the 2^-15 box padding (>= 16x the rounding error of t)
     const uint32_t c0 = f2bits(q3.x), c1 = f2bits(q3.y);
+#ifdef HJR_BRANCHLESS_NODE
+    const bool both = h0 & h1, any = h0 | h1;
+    const bool swap = lo1 < lo0;
+    const uint32_t nearc = both ? (swap ? c1 : c0) : (h0 ? c0 : c1);
+    if (both) stack[sp * BLOCK] = stack_enc<ST>(swap ? c0 : c1);
+    sp += both ? 1 : 0;
+    uint32_t popped = HJR_TRAV_DONE;
+    const bool do_pop = !any & (sp > 0);
+    if (do_pop) popped = stack_dec(stack[(sp - 1) * BLOCK]);
+    sp -= do_pop ? 1 : 0;
+    cur = any ? nearc : popped;
+    return 2u;
+#else
     if (h0 && h1) {
         const bool swap = lo1 < lo0;
         stack[sp * BLOCK] = stack_enc<ST>(swap ? c0 : c1);
@@ -622,6 +653,7 @@ HD uint32_t node_step(const float4* nodes, uint32_t& cur, const BoxRay& R, float
     else if (sp > 0) { sp--; cur = stack_dec(stack[sp * BLOCK]); }
     else cur = HJR_TRAV_DONE;
     return 2u;
+#endif
     } else {
     const float4* nd = nodes + cur * HJR_NODE4_F4;
     // near / far plane rows picked by the ray's direction signs: no min/max per axis

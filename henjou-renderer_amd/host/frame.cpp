@@ -173,6 +173,106 @@ struct Builder {
 
 } // namespace
 
+namespace {
+
+inline uint32_t leaf_ref(uint32_t first, uint32_t count) { return HJR_LEAF_FLAG | (count << 27) | first; }
+
+// BVH2: inner nodes depth-first; a root that is itself a leaf (one triangle) gets an empty sibling
+void emit_bvh2(const Builder& B, FrameData& out)
+{
+    std::vector<int> inner_id(B.nodes.size(), -1);
+    uint32_t n_inner = 0;
+    for (size_t i = 0; i < B.nodes.size(); i++)
+        if (B.nodes[i].left >= 0) inner_id[i] = (int)n_inner++;
+    if (n_inner == 0) {
+        out.nodes.assign(16, 0.0f);
+        const BuildNode& r = B.nodes[0];
+        float* q = out.nodes.data();
+        for (int c = 0; c < 2; c++)
+            for (int a = 0; a < 3; a++) { q[6 * c + a] = r.box.lo[a]; q[6 * c + 3 + a] = r.box.hi[a]; }
+        q[12] = u2f(leaf_ref(r.first, r.count));
+        q[13] = u2f(leaf_ref(0, 0));
+        out.n_nodes = 1;
+        out.stack_need = 2;
+        return;
+    }
+    out.nodes.assign((size_t)n_inner * 16, 0.0f);
+    out.n_nodes = n_inner;
+    out.stack_need = B.max_depth + 2;
+    for (size_t i = 0; i < B.nodes.size(); i++) {
+        if (inner_id[i] < 0) continue;
+        float* q = &out.nodes[(size_t)inner_id[i] * 16];
+        const int cid[2] = { B.nodes[i].left, B.nodes[i].right };
+        for (int c = 0; c < 2; c++) {
+            const BuildNode& ch = B.nodes[(size_t)cid[c]];
+            for (int a = 0; a < 3; a++) { q[6 * c + a] = ch.box.lo[a]; q[6 * c + 3 + a] = ch.box.hi[a]; }
+            q[12 + c] = u2f(ch.left >= 0 ? (uint32_t)inner_id[(size_t)cid[c]] : leaf_ref(ch.first, ch.count));
+        }
+    }
+}
+
+// BVH4: a wide node starts from the two children of a BVH2 inner node and repeatedly replaces its largest-area inner child by
+// that child's two children until it has four children (or only leaves).  Breadth-first ids: the top of the tree is contiguous.
+void emit_bvh4(const Builder& B, FrameData& out)
+{
+    struct Wide { int child[4]; int n; };
+    std::vector<Wide> wide;
+    std::vector<int> wide_of(B.nodes.size(), -1); // BVH2 inner node -> wide node id
+    auto make_wide = [&](int root2) {
+        Wide w;
+        w.n = 0;
+        if (B.nodes[(size_t)root2].left < 0) w.child[w.n++] = root2; // a single leaf: wide root with one leaf child
+        else { w.child[w.n++] = B.nodes[(size_t)root2].left; w.child[w.n++] = B.nodes[(size_t)root2].right; }
+        while (w.n < 4) {
+            int best = -1;
+            float barea = -1.0f;
+            for (int c = 0; c < w.n; c++) {
+                const BuildNode& ch = B.nodes[(size_t)w.child[c]];
+                if (ch.left >= 0 && ch.box.area() > barea) { barea = ch.box.area(); best = c; }
+            }
+            if (best < 0) break;
+            const int e = w.child[best];
+            w.child[best] = B.nodes[(size_t)e].left;
+            w.child[w.n++] = B.nodes[(size_t)e].right;
+        }
+        wide_of[(size_t)root2] = (int)wide.size();
+        wide.push_back(w);
+    };
+    make_wide(0);
+    for (size_t head = 0; head < wide.size(); head++)
+        for (int c = 0; c < wide[head].n; c++)
+            if (B.nodes[(size_t)wide[head].child[c]].left >= 0) make_wide(wide[head].child[c]);
+    out.n_nodes = (uint32_t)wide.size();
+    out.nodes.assign(wide.size() * (size_t)HJR_NODE4_F4 * 4, 0.0f);
+    for (size_t i = 0; i < wide.size(); i++) {
+        float* q = &out.nodes[i * (size_t)HJR_NODE4_F4 * 4];
+        for (int c = 0; c < 4; c++) {
+            if (c < wide[i].n) {
+                const BuildNode& ch = B.nodes[(size_t)wide[i].child[c]];
+                for (int a = 0; a < 3; a++) { q[8 * a + c] = ch.box.lo[a]; q[8 * a + 4 + c] = ch.box.hi[a]; }
+                q[24 + c] = u2f(ch.left >= 0 ? (uint32_t)wide_of[(size_t)wide[i].child[c]] : leaf_ref(ch.first, ch.count));
+            } else { // unused slot: inverted box, empty leaf
+                for (int a = 0; a < 3; a++) { q[8 * a + c] = 1e30f; q[8 * a + 4 + c] = -1e30f; }
+                q[24 + c] = u2f(leaf_ref(0, 0));
+            }
+        }
+    }
+    // exact worst-case traversal stack: every visited wide node can leave (children - 1) entries pending
+    std::vector<uint32_t> pend(wide.size(), 0);
+    uint32_t worst = 1;
+    for (size_t i = 0; i < wide.size(); i++) { // parents precede children (breadth-first ids)
+        const uint32_t here = pend[i] + (uint32_t)(wide[i].n > 0 ? wide[i].n - 1 : 0);
+        worst = std::max(worst, here);
+        for (int c = 0; c < wide[i].n; c++) {
+            const int ch = wide[i].child[c];
+            if (B.nodes[(size_t)ch].left >= 0) pend[(size_t)wide_of[(size_t)ch]] = here;
+        }
+    }
+    out.stack_need = worst + 1;
+}
+
+} // namespace
+
 bool build_frame(const SceneCopy& sc, const float* M, const float* Mi, uint32_t n_inst, bool allow_lds, FrameData& out, std::string& err)
 {
     if (n_inst != sc.n_instances) { err = "instance count does not match the uploaded scene"; return false; }
@@ -258,7 +358,6 @@ bool build_frame(const SceneCopy& sc, const float* M, const float* Mi, uint32_t 
         for (int a = 0; a < 3; a++) { B.tbox[t].lo[a] -= pad; B.tbox[t].hi[a] += pad; }
 
     out.tri_geom.assign((size_t)std::max(n, 1u) * HJR_TRI_F4 * 4, 0.0f);
-    auto leaf_ref = [](uint32_t first, uint32_t count) { return HJR_LEAF_FLAG | (count << 27) | first; };
     if (n == 0) { // empty scene: one BVH4 root with four empty slots
         out.width = 4; out.lds_mode = 0;
         out.nodes.assign((size_t)HJR_NODE4_F4 * 4, 0.0f);
@@ -297,99 +396,8 @@ bool build_frame(const SceneCopy& sc, const float* M, const float* Mi, uint32_t 
         out.width = (v == 2 || (v != 4 && lds_mode)) ? 2u : 4u;
     } else out.width = lds_mode ? 2u : 4u;
     out.lds_mode = lds_mode;
-    if (out.width == 2) {
-    // emit inner nodes depth-first; a root that is itself a leaf (n == 1) gets an empty sibling
-    std::vector<int> inner_id(B.nodes.size(), -1);
-    uint32_t n_inner = 0;
-    for (size_t i = 0; i < B.nodes.size(); i++) if (B.nodes[i].left >= 0) inner_id[i] = (int)n_inner++;
-    if (n_inner == 0) {
-        out.nodes.assign(16, 0.0f);
-        const BuildNode& r = B.nodes[0];
-        float* q = out.nodes.data();
-        q[0] = r.box.lo[0]; q[1] = r.box.lo[1]; q[2] = r.box.lo[2]; q[3] = r.box.hi[0]; q[4] = r.box.hi[1]; q[5] = r.box.hi[2];
-        q[6] = r.box.lo[0]; q[7] = r.box.lo[1]; q[8] = r.box.lo[2]; q[9] = r.box.hi[0]; q[10] = r.box.hi[1]; q[11] = r.box.hi[2];
-        q[12] = u2f(leaf_ref(r.first, r.count)); q[13] = u2f(leaf_ref(0, 0));
-        out.n_nodes = 1;
-        out.stack_need = 2;
-    } else {
-    out.nodes.assign((size_t)n_inner * 16, 0.0f);
-    out.n_nodes = n_inner;
-    out.stack_need = B.max_depth + 2;
-    for (size_t i = 0; i < B.nodes.size(); i++) {
-        if (inner_id[i] < 0) continue;
-        float* q = &out.nodes[(size_t)inner_id[i] * 16];
-        const BuildNode* ch[2] = { &B.nodes[(size_t)B.nodes[i].left], &B.nodes[(size_t)B.nodes[i].right] };
-        int cid[2] = { B.nodes[i].left, B.nodes[i].right };
-        for (int c = 0; c < 2; c++) {
-            for (int a = 0; a < 3; a++) { q[6 * c + a] = ch[c]->box.lo[a]; q[6 * c + 3 + a] = ch[c]->box.hi[a]; }
-            uint32_t ref = (ch[c]->left >= 0) ? (uint32_t)inner_id[(size_t)cid[c]] : leaf_ref(ch[c]->first, ch[c]->count);
-            q[12 + c] = u2f(ref);
-        }
-    }
-    }
-    } else {
-    // collapse the BVH2 into a BVH4: a wide node starts from the two children of a BVH2 inner node and repeatedly replaces its
-    // largest-area inner child by that child's two children until it has four children (or only leaves)
-    struct Wide { int child[4]; int n; };
-    std::vector<Wide> wide;
-    std::vector<int> wide_of(B.nodes.size(), -1); // BVH2 inner node -> wide node id
-    auto make_wide = [&](int root2) {
-        Wide w; w.n = 0;
-        if (B.nodes[(size_t)root2].left < 0) { w.child[w.n++] = root2; } // a single leaf (n == 1): wide root with one leaf child
-        else { w.child[w.n++] = B.nodes[(size_t)root2].left; w.child[w.n++] = B.nodes[(size_t)root2].right; }
-        while (w.n < 4) {
-            int best = -1; float barea = -1.0f;
-            for (int c = 0; c < w.n; c++) {
-                const BuildNode& ch = B.nodes[(size_t)w.child[c]];
-                if (ch.left >= 0 && ch.box.area() > barea) { barea = ch.box.area(); best = c; }
-            }
-            if (best < 0) break;
-            int e = w.child[best];
-            w.child[best] = B.nodes[(size_t)e].left;
-            w.child[w.n++] = B.nodes[(size_t)e].right;
-        }
-        wide_of[(size_t)root2] = (int)wide.size();
-        wide.push_back(w);
-        return (int)wide.size() - 1;
-    };
-    make_wide(0);
-    for (size_t head = 0; head < wide.size(); head++) { // breadth-first: the top of the tree is contiguous
-        for (int c = 0; c < wide[head].n; c++) {
-            int ch = wide[head].child[c];
-            if (B.nodes[(size_t)ch].left >= 0) make_wide(ch);
-        }
-    }
-    out.n_nodes = (uint32_t)wide.size();
-    out.nodes.assign(wide.size() * (size_t)HJR_NODE4_F4 * 4, 0.0f);
-    for (size_t i = 0; i < wide.size(); i++) {
-        float* q = &out.nodes[i * (size_t)HJR_NODE4_F4 * 4];
-        for (int c = 0; c < 4; c++) {
-            if (c < wide[i].n) {
-                const BuildNode& ch = B.nodes[(size_t)wide[i].child[c]];
-                for (int a = 0; a < 3; a++) { q[8 * a + c] = ch.box.lo[a]; q[8 * a + 4 + c] = ch.box.hi[a]; }
-                uint32_t ref = (ch.left >= 0) ? (uint32_t)wide_of[(size_t)wide[i].child[c]] : leaf_ref(ch.first, ch.count);
-                q[24 + c] = u2f(ref);
-            } else {
-                for (int a = 0; a < 3; a++) { q[8 * a + c] = 1e30f; q[8 * a + 4 + c] = -1e30f; }
-                q[24 + c] = u2f(leaf_ref(0, 0));
-            }
-        }
-    }
-    // exact worst-case traversal stack: every visited wide node can leave (children - 1) entries pending
-    {
-        std::vector<uint32_t> pend(wide.size(), 0);
-        uint32_t worst = 1;
-        for (size_t i = 0; i < wide.size(); i++) { // parents precede children (breadth-first ids)
-            uint32_t here = pend[i] + (uint32_t)(wide[i].n > 0 ? wide[i].n - 1 : 0);
-            worst = std::max(worst, here);
-            for (int c = 0; c < wide[i].n; c++) {
-                int ch = wide[i].child[c];
-                if (B.nodes[(size_t)ch].left >= 0) pend[(size_t)wide_of[(size_t)ch]] = here;
-            }
-        }
-        out.stack_need = worst + 1;
-    }
-    }
+    if (out.width == 2) emit_bvh2(B, out);
+    else emit_bvh4(B, out);
     return true;
 }
 

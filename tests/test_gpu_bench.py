@@ -1,0 +1,43 @@
+"""bench.py contract on a GPU: one JSON line with the required keys at N = 1, and a rehearsal of the N = 2 code path
+(two ranks pinned to the one GPU of the box, gloo instead of RCCL) — the driver's N = 2/4/8 runs use the same code with nccl."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from scene_util import ROOT
+
+pytestmark = pytest.mark.gpu
+REQUIRED = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config"]
+
+
+def run(cmd, env=None):
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_single_gpu_contract():
+    d = run([sys.executable, "bench.py", "--width", "320", "--height", "200", "--spp", "32", "--steps", "2", "--warmup", "1", "--cpu-spp", "2"])
+    for k in REQUIRED:
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["unit"] == "Msamples/s" and d["dtype"] == "f32"
+    assert d["value"] > 0 and d["higher_is_better"] is True and d["vs_baseline"] is None and "workload" in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "Msamples/s"
+
+
+def test_bench_two_rank_rehearsal():
+    env = dict(os.environ, HJR_BENCH_DEVICE="0", HJR_BENCH_BACKEND="gloo")
+    d = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+             "--master-port", "29577", "bench.py", "--gpus", "2", "--width", "320", "--height", "200", "--spp", "32", "--steps", "1",
+             "--warmup", "1"], env=env)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and "cpu_baseline" not in d
+    assert "reduce" in d["config"]["parallelism"]

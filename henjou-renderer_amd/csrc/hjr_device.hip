@@ -249,6 +249,7 @@ static int render_impl(hjr_ctx* c, const hjr_params* p, void* d_color, void* d_a
     if (!c || !p || !d_color) { set_error("hjr_render: null argument"); return HJR_ERR_ARG; }
     if (!c->have_scene || !c->have_frame) { set_error("hjr_render: upload a scene and set transforms first"); return HJR_ERR_STATE; }
     if (p->width == 0 || p->height == 0 || p->spp == 0) { set_error("hjr_render: width, height and spp must be positive"); return HJR_ERR_ARG; }
+    if (p->width > 8192 || p->height > 8192) { set_error("hjr_render: frames larger than 8192 x 8192 are not supported"); return HJR_ERR_ARG; }
     if (p->integrator > HJR_INTEGRATOR_MIS) { set_error("hjr_render: unknown integrator"); return HJR_ERR_ARG; }
     const uint32_t world = p->world_size ? p->world_size : 1u;
     if (p->rank >= world) { set_error("hjr_render: rank >= world_size"); return HJR_ERR_ARG; }
@@ -262,7 +263,7 @@ static int render_impl(hjr_ctx* c, const hjr_params* p, void* d_color, void* d_a
     if (n_items >= 0xffffffffull) { set_error("hjr_render: image too large"); return HJR_ERR_ARG; }
 
     // work area: [0] queue head, [16..] HJR_NSTAT uint64 counters
-    const size_t work_bytes = 16 + (HJR_NSTAT + 14) * 8; // +14: phase clocks / lane-occupancy sums of the HJR_TIMING diagnostic build
+    const size_t work_bytes = 16 + (HJR_NSTAT + 18) * 8; // +18: phase clocks / lane-occupancy sums of the HJR_TIMING diagnostic build
     if (c->d_work.cap < work_bytes) {
         std::vector<unsigned char> z(work_bytes, 0);
         if (!c->d_work.upload(z.data(), work_bytes, st)) { set_error("hjr_render: work buffer allocation failed"); return HJR_ERR_DEVICE; }
@@ -358,9 +359,11 @@ static int fetch_stats(hjr_ctx* c, hipStream_t st)
     for (int i = 0; i < HJR_NSTAT; i++) dst[i] = h[i];
 #ifdef HJR_TIMING
     {
-        unsigned long long tk[14];
+        unsigned long long tk[18];
         HIPCHK(hipMemcpy(tk, (char*)c->d_work.p + 16 + HJR_NSTAT * 8, sizeof(tk), hipMemcpyDeviceToHost));
         double tot = 0; for (int i = 0; i < 6; i++) tot += (double)tk[i];
+        for (int i = 14; i < 18; i++) tot += (double)tk[i];
+        fprintf(stderr, "[hjr timing]   finer: refill %.1f%%  resolve shadow/finish %.1f%%  hit program %.1f%%\n", 100 * tk[14] / tot, 100 * tk[15] / tot, 100 * tk[16] / tot);
         fprintf(stderr, "[hjr timing] rr/regen %.1f%%  trace %.1f%%  resolve+hit %.1f%%  nee(light+eval) %.1f%%  bsdf sample %.1f%%  rest %.1f%%  (total %.3g wave-clocks)\n",
                 100 * tk[0] / tot, 100 * tk[1] / tot, 100 * tk[2] / tot, 100 * tk[3] / tot, 100 * tk[4] / tot, 100 * tk[5] / tot, tot);
         if (tk[8]) fprintf(stderr, "[hjr timing]   lanes per wave iteration: closest ray %.1f, shadow ray %.1f, shading %.1f (msGGX %.1f, glass %.1f); shading executed in %.0f%% of iterations\n",

@@ -922,10 +922,9 @@ HD void start_path(const KParams& P, PathState& ps, uint32_t px, uint32_t py, ui
     f3 cd = V(P.cam_dir[0], P.cam_dir[1], P.cam_dir[2]);
     f3 cu = V(P.cam_up[0], P.cam_up[1], P.cam_up[2]);
     f3 cr = V(P.cam_right[0], P.cam_right[1], P.cam_right[2]);
-    ps.ro = V(P.cam_pos[0], P.cam_pos[1], P.cam_pos[2]);
+    // the ray origin is the (wave-uniform) camera position: not stored per lane, see `fresh` in the kernel
     ps.rd = normalize(cd * P.cam_f + cr * u + cu * v);
     ps.thr = V1(1.0f);
-    ps.L = V1(0.0f);
     ps.depth = 0;
 }
 
@@ -965,11 +964,20 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
     bool fin_pending = false;   // a finished path whose L still waits for its last NEE shadow ray
     bool write_pending = false; // the item's last sample is finished; sums go out once fin_pending is resolved
     bool sh_valid = false;      // pending NEE shadow ray of the bounce shaded in the previous iteration
-    uint32_t px = 0, py = 0, s = 0, s_end = 0, chunk = 0;
+    // Register diet (the LDS variant runs at 128 VGPRs): pixel and chunk share one word; ps.ro doubles as the origin of the
+    // pending shadow ray (a regenerated path starts at the wave-uniform camera position: `fresh`); ps.L keeps the finished
+    // path's radiance while fin_pending (the new path's L is 0 until that is resolved).
+    bool fresh = true;          // the closest-hit ray of this lane starts at the camera
+    uint32_t item = 0;          // px | py << 13 | chunk << 26
+    uint32_t s = 0;
     uint32_t w_next = 0, w_end = 0; // this wave's private item range (wave-uniform)
     f3 sumL = V1(0.0f), sumA = V1(0.0f), sumN = V1(0.0f);
-    f3 sh_o = V1(0.0f), sh_d = V1(0.0f), sh_contrib = V1(0.0f), fin_L = V1(0.0f);
+    f3 sh_d = V1(0.0f), sh_contrib = V1(0.0f);
     float sh_tmax = 0.0f;
+#define HJR_PX (item & 0x1fffu)
+#define HJR_PY ((item >> 13) & 0x1fffu)
+#define HJR_CHUNK (item >> 26)
+#define HJR_S_END min((HJR_CHUNK + 1u) * P.chunk_spp, P.spp)
     PathState ps;
     ps.ro = ps.rd = ps.thr = ps.L = V1(0.0f);
     ps.depth = 0;
@@ -977,12 +985,14 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
     const float inv_spp = 1.0f / (float)P.spp;
 #ifdef HJR_TIMING
     // diagnostic build: wave-clock shares of the loop's phases, summed per wave into P.stats[10..15] (never in the shipped build)
-    unsigned long long tk[6] = { 0, 0, 0, 0, 0, 0 }, tk6 = 0, tk7 = 0;
+    unsigned long long tk[6] = { 0, 0, 0, 0, 0, 0 }, tk6 = 0, tk7 = 0, tx[4] = { 0, 0, 0, 0 };
+#define HJR_TICKX(i) { __builtin_amdgcn_sched_barrier(0); unsigned long long now_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); tx[i] += now_ - tstamp; tstamp = now_; }
     unsigned long long oc[6] = { 0, 0, 0, 0, 0, 0 }; // wave iterations, lanes tracing closest, lanes with a shadow ray, lanes shading, msGGX lanes, glass lanes
     unsigned long long tstamp = __builtin_amdgcn_s_memtime();
 #define HJR_TICK(i) { __builtin_amdgcn_sched_barrier(0); unsigned long long now_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); tk[i] += now_ - tstamp; tstamp = now_; }
 #else
 #define HJR_TICK(i)
+#define HJR_TICKX(i)
 #endif
 
     for (;;) {
@@ -1010,14 +1020,14 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
                         // tile and one sample chunk (coherent primary rays)
                         const uint32_t tc = q >> 6;
                         const uint32_t tile = (tc / P.n_chunks) * P.world + P.rank;
-                        chunk = tc % P.n_chunks;
+                        const uint32_t chunk = tc % P.n_chunks;
                         const uint32_t tx = tile % P.tiles_x, ty = tile / P.tiles_x;
-                        px = tx * HJR_TILE + (q & 7u);
-                        py = ty * HJR_TILE + ((q >> 3) & 7u);
+                        const uint32_t px = tx * HJR_TILE + (q & 7u);
+                        const uint32_t py = ty * HJR_TILE + ((q >> 3) & 7u);
                         if (px < P.width && py < P.height) {
                             has_item = true; path_live = false;
+                            item = px | (py << 13) | (chunk << 26);
                             s = chunk * P.chunk_spp;
-                            s_end = min(s + P.chunk_spp, P.spp);
                             sumL = V1(0.0f); sumA = V1(0.0f); sumN = V1(0.0f);
                         }
                     } else dead = true;
@@ -1026,6 +1036,7 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
             if (__ballot(!dead) == 0ull) break; // a lane only dies with nothing pending
         }
 
+        HJR_TICKX(0)
         // NaN/Inf guard + ordered accumulation of one finished sample
         auto finish_sample = [&](f3 L) {
             float sum = L.x + L.y + L.z;
@@ -1037,16 +1048,16 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
         auto close_sample = [&]() {
             s++;
             path_live = false;
-            if (s == s_end) { write_pending = true; has_item = false; }
+            if (s == HJR_S_END) { write_pending = true; has_item = false; }
         };
         auto write_out = [&]() {
-            const size_t pix = (size_t)px + (size_t)py * P.width;
+            const size_t pix = (size_t)HJR_PX + (size_t)HJR_PY * P.width;
             if (P.n_chunks == 1u) { // the item is the whole pixel: mean = chunk sum * (1 / spp)
                 P.aov_color[pix] = make_float4(sumL.x * inv_spp, sumL.y * inv_spp, sumL.z * inv_spp, 1.0f);
                 if (AOVS && P.aov_albedo) P.aov_albedo[pix] = make_float4(sumA.x * inv_spp, sumA.y * inv_spp, sumA.z * inv_spp, 1.0f);
                 if (AOVS && P.aov_normal) P.aov_normal[pix] = make_float4(sumN.x * inv_spp, sumN.y * inv_spp, sumN.z * inv_spp, 1.0f);
             } else { // chunk sum -> HBM; hjr_finalize_kernel adds the chunks of a pixel in chunk order
-                const size_t slot = (size_t)chunk * ((size_t)P.width * P.height) + pix;
+                const size_t slot = (size_t)HJR_CHUNK * ((size_t)P.width * P.height) + pix;
                 P.part_color[slot] = make_float4(sumL.x, sumL.y, sumL.z, 0.0f);
                 if (AOVS && P.part_albedo) P.part_albedo[slot] = make_float4(sumA.x, sumA.y, sumA.z, 0.0f);
                 if (AOVS && P.part_normal) P.part_normal[slot] = make_float4(sumN.x, sumN.y, sumN.z, 0.0f);
@@ -1059,12 +1070,16 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
         //      radiance is final only after its pending shadow ray (fused into the same trace) is resolved.
         bool tracing = false;
         while (has_item) {
-            if (!path_live) { start_path(P, ps, px, py, s); path_live = true; }
+            if (!path_live) {
+                start_path(P, ps, HJR_PX, HJR_PY, s);
+                if (!fin_pending) ps.L = V1(0.0f); // while fin_pending, ps.L still belongs to the finished path
+                path_live = true; fresh = true;
+            }
             const float russian_p = fmaxf(ps.thr.x, fmaxf(ps.thr.y, ps.thr.z));
-            CMJState rr = path_rng(P, px, py, s, ps.rng_depth);
+            CMJState rr = path_rng(P, HJR_PX, HJR_PY, s, ps.rng_depth);
             const float xi_rr = cmj_1d(rr);
             ps.rng_depth = rr.depth;
-            if (russian_p < xi_rr) { fin_pending = true; fin_L = ps.L; close_sample(); continue; }
+            if (russian_p < xi_rr) { fin_pending = true; close_sample(); continue; }
             ps.thr = ps.thr / russian_p;
             tracing = true;
             break;
@@ -1079,7 +1094,8 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
         Hit h;
         {
             Counters ca, cb; ca.box = ca.tri = cb.box = cb.tri = 0;
-            traverse_fused<STATS, WIDTH, BLOCK, ST>(nodes, tris, sh_valid, sh_o, sh_d, sh_tmax, tracing, ps.ro, ps.rd, occluded, h, stack, ca, cb);
+            const f3 cam_o = V(P.cam_pos[0], P.cam_pos[1], P.cam_pos[2]);
+            traverse_fused<STATS, WIDTH, BLOCK, ST>(nodes, tris, sh_valid, ps.ro, sh_d, sh_tmax, tracing, fresh ? cam_o : ps.ro, ps.rd, occluded, h, stack, ca, cb);
 #ifdef HJR_TIMING
             tk6 += ca.t_node; tk7 += ca.t_leaf;
 #endif
@@ -1090,21 +1106,21 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
         }
         HJR_TICK(1)
         if (sh_valid) { // `if (!light_shot.is_hit) LTE += ...` (rt.h:245-259), added to the path the shadow ray belongs to
-            if (!occluded) {
-                if (fin_pending) fin_L = fin_L + sh_contrib;
-                else ps.L = ps.L + sh_contrib;
-            }
+            if (!occluded) ps.L = ps.L + sh_contrib; // ps.L is the finished path's radiance while fin_pending
             sh_valid = false;
         }
         if (fin_pending) {
-            finish_sample(fin_L);
+            finish_sample(ps.L);
+            ps.L = V1(0.0f); // from here on ps.L belongs to the path that was regenerated (or to nothing)
             fin_pending = false;
             if (write_pending) write_out();
         }
+        HJR_TICKX(1)
 
         if (tracing) {
             HitInfo prd;
             hit_program<STATS, AOVS>(P, tris, h, ps.rd, prd, lc);
+            HJR_TICKX(2)
             if (AOVS && ps.depth == 0) { sumA = sumA + prd.surf.basecolor; sumN = sumN + prd.normal; } // rt.h:191-194
             if (!prd.is_hit || prd.is_light) {
                 // NEE / MIS count emission only at depth 0 (rt.h:196-208, 318-330); Pathtrace always (rt.h:118-126)
@@ -1117,7 +1133,7 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
 #ifdef HJR_TIMING
                 oc[3] += __popcll(__ballot(true)); oc[4] += __popcll(__ballot(!prd.surf.is_specular && prd.surf.metallic > 0.5f)); oc[5] += __popcll(__ballot(prd.surf.is_specular));
 #endif
-                CMJState st = path_rng(P, px, py, s, ps.rng_depth);
+                CMJState st = path_rng(P, HJR_PX, HJR_PY, s, ps.rng_depth);
                 const Surface& sf = prd.surf;
                 f3 t, b;
                 const f3 n = prd.normal;
@@ -1154,7 +1170,7 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
                         const float mis_weight = light_pdf / (light_pdf + pt_pdf);
                         sh_contrib = ((ps.thr * ((bsdf * G * cosine1) / light_pdf)) * mis_weight) * light_color; // rt.h:378
                     }
-                    sh_o = so; sh_d = sd; sh_tmax = light_distance - 0.001f;
+                    sh_d = sd; sh_tmax = light_distance - 0.001f; // origin = prd.position = ps.ro below
                     // an exactly-zero contribution (every hit on the glass lobe, whose evaluateBSDF is 0) cannot change L whatever
                     // the shadow ray returns (x + 0 == x): skip the trace.  A NaN contribution still goes through.
                     sh_valid = !(sh_contrib.x == 0.0f && sh_contrib.y == 0.0f && sh_contrib.z == 0.0f);
@@ -1166,7 +1182,7 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
                     if (sh_valid) {
                         Hit shh;
                         Counters c; c.box = 0; c.tri = 0;
-                        const bool occ = traverse<true, STATS, WIDTH, BLOCK, ST>(nodes, tris, sh_o, sh_d, 0.001f, sh_tmax, shh, stack, c);
+                        const bool occ = traverse<true, STATS, WIDTH, BLOCK, ST>(nodes, tris, prd.position, sh_d, 0.001f, sh_tmax, shh, stack, c);
                         if (STATS) { lc[2] += 1; lc[5] += c.box; lc[6] += c.tri; }
                         if (!occ) ps.L = ps.L + sh_contrib;
                         sh_valid = false;
@@ -1217,10 +1233,11 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
                 ps.thr = ps.thr * ((bsdf * fabsf(dot(wi, n))) / pdf); // rt.h:274
                 ps.ro = prd.position;
                 ps.rd = wi;
+                fresh = false;
                 ps.rng_depth = st.depth;
                 ps.depth++;
                 if (ps.depth == 10) { // MaxDepth (rt.h:166): the path is over, its last shadow ray is still pending
-                    fin_pending = true; fin_L = ps.L;
+                    fin_pending = true;
                     close_sample();
                 }
                 HJR_TICK(4)
@@ -1231,6 +1248,7 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
 #ifdef HJR_TIMING
     if (lane == 0) { for (int i = 0; i < 6; i++) atomicAdd(&P.stats[HJR_NSTAT + i], tk[i]); atomicAdd(&P.stats[HJR_NSTAT + 6], tk6); atomicAdd(&P.stats[HJR_NSTAT + 7], tk7); }
     if (__ffsll((long long)__ballot(true)) - 1 == (int)lane) for (int i = 0; i < 6; i++) atomicAdd(&P.stats[HJR_NSTAT + 8 + i], oc[i]);
+    if (lane == 0) for (int i = 0; i < 4; i++) atomicAdd(&P.stats[HJR_NSTAT + 14 + i], tx[i]);
 #endif
 
     if (STATS) {

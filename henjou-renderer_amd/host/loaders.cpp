@@ -1,8 +1,10 @@
 // Scene surface: render_option.json and glTF 2.0 loaders + per-frame animation / camera evaluation.
 // Restates loader/render_json_loader.h:14-228, loader/gltfloader.h:1068-1601, renderer/renderer.h:257-291,1145-1169
 // on top of the local JSON parser (the reference's nlohmann/json, tinygltf and glm are un-vendored submodules).
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <ctime>
 #include <fstream>
 #include <map>
 #include <sstream>
@@ -99,6 +101,15 @@ bool load_render_option(const std::string& path, hjr_render_option& o, std::stri
         o.save_renderOption = op.at("save_renderOption").as_bool() ? 1 : 0;
 
         put_str(o.LUT_path, sizeof(o.LUT_path), j.at("LUT").at("LUT_path").as_string());
+
+        if (o.save_renderOption) { // render_json_loader.h:204-219: timestamped copy of the JSON text in the CWD
+            std::time_t now = std::time(nullptr);
+            std::string stamp = std::ctime(&now);
+            stamp.erase(std::remove(stamp.begin(), stamp.end(), ':'), stamp.end());
+            stamp.erase(std::remove(stamp.begin(), stamp.end(), '\n'), stamp.end());
+            std::ofstream file("renderoption" + stamp + ".json");
+            file << text;
+        }
 
         if (const Json* h = j.find("Henjou_HIP")) { // extension section; the reference never reads it
             o.seed = (uint32_t)h->number_or("seed", 1);

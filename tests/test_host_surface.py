@@ -61,6 +61,16 @@ def test_render_option_errors_and_fps_override(tmp_path):
     finally:
         os.chdir(cwd)
     assert o.render_mode == 0 and o.seed == 77 and o.integrator == hjr.INTEGRATOR_MIS and o.fps == 30
+    # Option.save_renderOption: a timestamped copy of the JSON text lands in the CWD (render_json_loader.h:204-219)
+    ok["Option"]["save_renderOption"] = True
+    (tmp_path / "save.json").write_text(json.dumps(ok))
+    os.chdir(tmp_path)
+    try:
+        hjr.load_render_option("save.json")
+    finally:
+        os.chdir(cwd)
+    copies = [f for f in os.listdir(tmp_path) if f.startswith("renderoption") and f.endswith(".json")]
+    assert len(copies) == 1 and json.load(open(tmp_path / copies[0])) == ok
 
 
 def test_gltf_loader_matches_independent_reader():

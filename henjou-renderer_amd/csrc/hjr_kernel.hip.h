@@ -729,24 +729,46 @@ HD bool traverse(const float4* nodes, const float4* tris, f3 o, f3 d, float tmin
 // resolved, without waiting for the rest of the wave, so the wave's trip count is max_lanes(tripsA + tripsB) instead of
 // max(tripsA) + max(tripsB) — the SIMT cost of per-lane trip-count variance drops by ~1/3 (profiles/r01_experiments.md).
 // Results are identical to two separate traversals.
+//
+// Straggler carry-over (HJR_CARRY > 0): the loop also ends when at most HJR_CARRY lanes are still traversing (and at least
+// one lane of this round has finished).  Those lanes keep their traversal state (TravCarry + hit + their LDS stack column),
+// skip the shading that follows and resume in the next round next to the other lanes' new rays: the wave's trip count per
+// round is set by the (64 - HJR_CARRY)-th slowest lane instead of the slowest one.  Per-lane results do not change.
+#ifndef HJR_CARRY
+#define HJR_CARRY 8
+#endif
+struct TravCarry { uint32_t cur; int sp, phase; };
 template <bool STATS, int WIDTH, int BLOCK, typename ST>
-HD void traverse_fused(const float4* nodes, const float4* tris, const bool a_valid, const f3 ao, const f3 ad, const float a_tmax, const bool b_valid,
-                       const f3 bo, const f3 bd, bool& occluded, Hit& hit, ST* stack, Counters& ca, Counters& cb)
+HD bool traverse_fused(const float4* nodes, const float4* tris, const bool a_valid, const f3 ao, const f3 ad, const float a_tmax, const bool b_valid,
+                       const f3 bo, const f3 bd, bool& occluded, Hit& hit, ST* stack, Counters& ca, Counters& cb, const bool resume, TravCarry& tc)
 {
     const float tmin = 0.001f;
-    occluded = false;
-    hit.prim = 0xffffffffu;
-    hit.t = 1e16f;
-    int phase = a_valid ? 0 : (b_valid ? 1 : 2);
+    int phase, sp;
+    uint32_t cur;
+    if (HJR_CARRY > 0 && resume) { phase = tc.phase; sp = tc.sp; cur = tc.cur; } // occluded / hit are the caller's, kept across rounds
+    else {
+        occluded = false;
+        hit.prim = 0xffffffffu;
+        hit.t = 1e16f;
+        phase = a_valid ? 0 : (b_valid ? 1 : 2);
+        sp = 0;
+        cur = (phase < 2) ? 0u : HJR_TRAV_DONE;
+    }
     f3 o = (phase == 0) ? ao : bo;
     f3 d = (phase == 0) ? ad : bd;
     BoxRay R = box_ray(o, d);
-    int sp = 0;
-    uint32_t cur = (phase < 2) ? 0u : HJR_TRAV_DONE;
+    const int n_start = HJR_CARRY > 0 ? __popcll(__ballot(phase < 2)) : 0;
 #ifdef HJR_TIMING
     unsigned long long t_node = 0, t_leaf = 0, t_last = __builtin_amdgcn_s_memtime();
 #endif
-    while (phase < 2) {
+#if HJR_CARRY > 0
+    for (;;) {
+        const int n_act = __popcll(__ballot(phase < 2));
+        if (n_act == 0 || (n_act <= HJR_CARRY && n_act < n_start)) break;
+        if (phase < 2) {
+#else
+    while (phase < 2) { {
+#endif
         // "while-while" traversal: every lane first descends through inner nodes until it holds a leaf (or is out of work) ...
         while (!(cur & HJR_LEAF_FLAG)) {
             const float tfar = (phase == 0) ? a_tmax : hit.t;
@@ -791,10 +813,12 @@ HD void traverse_fused(const float4* nodes, const float4* tris, const bool a_val
 #ifdef HJR_TIMING
         { __builtin_amdgcn_sched_barrier(0); unsigned long long now_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); t_leaf += now_ - t_last; t_last = now_; }
 #endif
-    }
+    } }
 #ifdef HJR_TIMING
     ca.t_node = t_node; ca.t_leaf = t_leaf;
 #endif
+    if (HJR_CARRY > 0) { tc.phase = phase; tc.sp = sp; tc.cur = cur; return phase < 2; }
+    return false;
 }
 
 // ------------------------------------------------------------------ closest-hit / miss programs (build-defined)
@@ -968,6 +992,10 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
     // pending shadow ray (a regenerated path starts at the wave-uniform camera position: `fresh`); ps.L keeps the finished
     // path's radiance while fin_pending (the new path's L is 0 until that is resolved).
     bool fresh = true;          // the closest-hit ray of this lane starts at the camera
+    bool inflight = false;      // HJR_CARRY: this lane's traversal continues in the next round (it skips everything else)
+    bool tracing = false, occluded = false;
+    Hit h;
+    TravCarry tc; tc.cur = HJR_TRAV_DONE; tc.sp = 0; tc.phase = 2;
     uint32_t item = 0;          // px | py << 13 | chunk << 26
     uint32_t s = 0;
     uint32_t w_next = 0, w_end = 0; // this wave's private item range (wave-uniform)
@@ -990,6 +1018,10 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
     unsigned long long oc[6] = { 0, 0, 0, 0, 0, 0 }; // wave iterations, lanes tracing closest, lanes with a shadow ray, lanes shading, msGGX lanes, glass lanes
     unsigned long long tstamp = __builtin_amdgcn_s_memtime();
 #define HJR_TICK(i) { __builtin_amdgcn_sched_barrier(0); unsigned long long now_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); tk[i] += now_ - tstamp; tstamp = now_; }
+#elif defined(HJR_MARK)
+// static-analysis build: region markers in the ISA listing (count instructions between them), never shipped
+#define HJR_TICK(i) { __builtin_amdgcn_sched_barrier(0); asm volatile("; HJRMARK T" #i); __builtin_amdgcn_sched_barrier(0); }
+#define HJR_TICKX(i) { __builtin_amdgcn_sched_barrier(0); asm volatile("; HJRMARK X" #i); __builtin_amdgcn_sched_barrier(0); }
 #else
 #define HJR_TICK(i)
 #define HJR_TICKX(i)
@@ -1068,21 +1100,24 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
         // ---- Russian roulette (rt.h:173-179) with in-place path regeneration: a lane whose path dies here starts its
         //      next sample immediately, so it still has a closest-hit ray for this iteration's trace.  The dead path's
         //      radiance is final only after its pending shadow ray (fused into the same trace) is resolved.
-        bool tracing = false;
-        while (has_item) {
-            if (!path_live) {
+        if (!inflight) {
+            if (has_item && path_live) { // continuing path
+                const float russian_p = fmaxf(ps.thr.x, fmaxf(ps.thr.y, ps.thr.z));
+                CMJState rr = path_rng(P, HJR_PX, HJR_PY, s, ps.rng_depth);
+                const float xi_rr = cmj_1d(rr);
+                ps.rng_depth = rr.depth;
+                if (russian_p < xi_rr) { fin_pending = true; close_sample(); }
+                else ps.thr = ps.thr / russian_p;
+            }
+            if (has_item && !path_live) {
                 start_path(P, ps, HJR_PX, HJR_PY, s);
                 if (!fin_pending) ps.L = V1(0.0f); // while fin_pending, ps.L still belongs to the finished path
                 path_live = true; fresh = true;
+                // the new path's own roulette draw: throughput is (1,1,1), so russian_p = 1 > xi for every xi in [0,1) and
+                // thr / 1 == thr; only the stream position moves
+                ps.rng_depth += 1u;
             }
-            const float russian_p = fmaxf(ps.thr.x, fmaxf(ps.thr.y, ps.thr.z));
-            CMJState rr = path_rng(P, HJR_PX, HJR_PY, s, ps.rng_depth);
-            const float xi_rr = cmj_1d(rr);
-            ps.rng_depth = rr.depth;
-            if (russian_p < xi_rr) { fin_pending = true; close_sample(); continue; }
-            ps.thr = ps.thr / russian_p;
-            tracing = true;
-            break;
+            tracing = has_item;
         }
 
         HJR_TICK(0)
@@ -1090,21 +1125,20 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
         oc[0] += 1; oc[1] += __popcll(__ballot(tracing)); oc[2] += __popcll(__ballot(sh_valid));
 #endif
         // ---- one fused traversal: pending shadow ray (TraceOcculution, rt.h:236-243) then closest-hit ray (RayTrace, rt.h:182-189)
-        bool occluded = false;
-        Hit h;
         {
             Counters ca, cb; ca.box = ca.tri = cb.box = cb.tri = 0;
             const f3 cam_o = V(P.cam_pos[0], P.cam_pos[1], P.cam_pos[2]);
-            traverse_fused<STATS, WIDTH, BLOCK, ST>(nodes, tris, sh_valid, ps.ro, sh_d, sh_tmax, tracing, fresh ? cam_o : ps.ro, ps.rd, occluded, h, stack, ca, cb);
+            inflight = traverse_fused<STATS, WIDTH, BLOCK, ST>(nodes, tris, sh_valid, ps.ro, sh_d, sh_tmax, tracing, fresh ? cam_o : ps.ro, ps.rd, occluded, h, stack, ca, cb, inflight, tc);
 #ifdef HJR_TIMING
             tk6 += ca.t_node; tk7 += ca.t_leaf;
 #endif
-            if (STATS) {
-                if (sh_valid) { lc[2] += 1; lc[5] += ca.box; lc[6] += ca.tri; }
-                if (tracing) { lc[1] += 1; lc[3] += cb.box; lc[4] += cb.tri; }
+            if (STATS) { // tests are counted round by round, rays when they are resolved
+                lc[5] += ca.box; lc[6] += ca.tri; lc[3] += cb.box; lc[4] += cb.tri;
+                if (!inflight) { if (sh_valid) lc[2] += 1; if (tracing) lc[1] += 1; }
             }
         }
         HJR_TICK(1)
+        if (inflight) continue;
         if (sh_valid) { // `if (!light_shot.is_hit) LTE += ...` (rt.h:245-259), added to the path the shadow ray belongs to
             if (!occluded) ps.L = ps.L + sh_contrib; // ps.L is the finished path's radiance while fin_pending
             sh_valid = false;

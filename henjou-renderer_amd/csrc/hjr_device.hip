@@ -202,7 +202,7 @@ template <int I, bool S, int W, bool A> static int launch_mem2(const hjr_ctx* c,
 // lds_mode: 0 = BVH4 read from memory, 1 = BVH2 staged in LDS with 32-bit stack entries, 2 = with 16-bit entries, 3 = BVH2 from memory
 template <int I, bool S, bool S16, bool A> static int launch_lds2(const hjr_ctx* c, const KParams& kp, uint64_t n_items, hipStream_t st)
 {
-    const size_t smem = (((size_t)HJR_BLOCK_LDS * kp.stack_depth * (S16 ? 2 : 4) + 15) / 16) * 16 + ((size_t)kp.n_node_f4 + kp.n_tri_f4) * 16;
+    const size_t smem = (((size_t)HJR_BLOCK_LDS * kp.stack_depth * (S16 ? 2 : 4) + 15) / 16) * 16 + ((size_t)kp.n_node_f4 + kp.n_tri_f4 + kp.n_mat_f4 + kp.n_light_f4) * 16;
     auto kern = hjr_render_kernel<I, S, HJR_BLOCK_LDS, true, S16, 2, A>;
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return -1;
     uint64_t blocks = (uint64_t)c->n_cus;
@@ -324,6 +324,8 @@ static int render_impl(hjr_ctx* c, const hjr_params* p, void* d_color, void* d_a
     kp.n_node_f4 = c->frame.n_nodes * (c->frame.width == 2 ? HJR_NODE2_F4 : HJR_NODE4_F4);
     kp.n_tri_f4 = (c->frame.n_tris ? c->frame.n_tris : 1u) * HJR_TRI_F4;
     kp.stack_depth = c->frame.stack_need; // exact worst case for this tree (host/frame.cpp)
+    kp.n_mat_f4 = (uint32_t)c->scene.materials.size() * HJR_MAT_F4;
+    kp.n_light_f4 = c->frame.n_lights * HJR_LIGHT_F4;
     // node format / LDS staging were decided by the host builder for this frame (host/frame.cpp)
     int lds_mode = c->frame.lds_mode;
     if (lds_mode == 0 && c->frame.width == 2) lds_mode = 3;

@@ -44,6 +44,7 @@ struct KParams {
     uint32_t rank, world;
     uint32_t chunk_spp, n_chunks;    // samples per work item, work items per pixel (hjr_chunking)
     uint32_t n_node_f4, n_tri_f4;    // float4 counts of nodes[] / tri_geom[] (LDS staging)
+    uint32_t n_mat_f4, n_light_f4;   // float4 counts of materials[] / lights[] (staged behind the triangles in the LDS variant)
     uint32_t stack_depth;            // traversal stack entries per lane (BVH depth + 1)
     float4* part_color;              // [n_chunks][height][width] chunk sums when n_chunks > 1
     float4* part_albedo;
@@ -831,7 +832,7 @@ struct HitInfo { // the Payload fields the integrators read (kernel/Payload.h:12
 
 // __closesthit__ch / __miss__ms for a finished closest-hit traversal
 template <bool STATS, bool FULL>
-HD void hit_program(const KParams& P, const float4* tris, const Hit& h, const f3 rd, HitInfo& prd, unsigned long long* lc)
+HD void hit_program(const KParams& P, const float4* tris, const float4* mats, const Hit& h, const f3 rd, HitInfo& prd, unsigned long long* lc)
 {
     if (h.prim == 0xffffffffu) { // __miss__ms: constant sky (use_IBL = false: 1x1 texel scene_sky_default, renderer.h:802-851) * ibl_intensity
         prd.is_hit = false; prd.is_light = false;
@@ -854,7 +855,7 @@ HD void hit_program(const KParams& P, const float4* tris, const Hit& h, const f3
     prd.is_hit = true;
     prd.position = V(g0.x, g0.y, g0.z) * w0 + V(g0.w, g1.x, g1.y) * h.b1 + V(g1.z, g1.w, g2.x) * h.b2;
     prd.normal = V(s0.x, s0.y, s0.z) * w0 + V(s1.x, s1.y, s1.z) * h.b1 + V(s2.x, s2.y, s2.z) * h.b2;
-    const float4* m = P.materials + (size_t)f2bits(s3.w) * HJR_MAT_F4;
+    const float4* m = mats + f2bits(g2.z) * HJR_MAT_F4; // g2.z == s3.w (material id): this fetch does not wait for the shading record
     const float4 m0 = m[0], m1 = m[1], m2 = m[2], m3 = m[3];
     prd.surf.basecolor = V(m0.x, m0.y, m0.z);
     prd.surf.metallic = m0.w;
@@ -882,22 +883,22 @@ HD void hit_program(const KParams& P, const float4* tris, const Hit& h, const f3
 
 // RayTrace (rt.h:43-69): stand-alone closest-hit query (used by MIS' BSDF-sampled light ray)
 template <bool STATS, bool FULL, int WIDTH, int BLOCK, typename ST>
-HD void ray_trace(const KParams& P, const float4* nodes, const float4* tris, f3 o, f3 d, HitInfo& prd, ST* stack, unsigned long long* lc)
+HD void ray_trace(const KParams& P, const float4* nodes, const float4* tris, const float4* mats, f3 o, f3 d, HitInfo& prd, ST* stack, unsigned long long* lc)
 {
     Hit h;
     Counters c; c.box = 0; c.tri = 0;
     traverse<false, STATS, WIDTH, BLOCK, ST>(nodes, tris, o, d, 0.001f, 1e16f, h, stack, c);
     if (STATS) { lc[1] += 1; lc[3] += c.box; lc[4] += c.tri; }
-    hit_program<STATS, FULL>(P, tris, h, d, prd, lc);
+    hit_program<STATS, FULL>(P, tris, mats, h, d, prd, lc);
 }
 
 // light_sample (kernel/light_sample.h:9-75) on the per-frame light table
-HD f3 light_sample(const KParams& P, CMJState& st, float& pdf, f3& normal, f3& emission)
+HD f3 light_sample(const KParams& P, const float4* lights, CMJState& st, float& pdf, f3& normal, f3& emission)
 {
     float p = cmj_1d(st);
     int index = (int)(p * P.n_lights);
     if (index == (int)P.n_lights) index--;
-    const float4* L = P.lights + (size_t)index * HJR_LIGHT_F4;
+    const float4* L = lights + (size_t)index * HJR_LIGHT_F4;
     const float4 l0 = L[0], l1 = L[1], l2 = L[2], l3 = L[3], l4 = L[4], l5 = L[5];
     f2 xi = cmj_2d(st);
     float f1 = 1.0f - sqrtf(xi.x);
@@ -971,14 +972,23 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
     const uint32_t lane = threadIdx.x & 63u;
     const float4* nodes = P.nodes;
     const float4* tris = P.tri_geom;
+    const float4* mats = P.materials;
+    const float4* lights = P.lights;
     if (LDSBVH) {
         float4* l_nodes = hjr_smem + (BLOCK * P.stack_depth * (uint32_t)sizeof(ST) + 15u) / 16u;
         float4* l_tris = l_nodes + P.n_node_f4;
         for (uint32_t i = threadIdx.x; i < P.n_node_f4; i += BLOCK) l_nodes[i] = P.nodes[i];
         for (uint32_t i = threadIdx.x; i < P.n_tri_f4; i += BLOCK) l_tris[i] = P.tri_geom[i];
+        // the (small) material and light tables ride along: one LDS read instead of an L2 round trip per shaded hit
+        float4* l_mats = l_tris + P.n_tri_f4;
+        float4* l_lights = l_mats + P.n_mat_f4;
+        for (uint32_t i = threadIdx.x; i < P.n_mat_f4; i += BLOCK) l_mats[i] = P.materials[i];
+        for (uint32_t i = threadIdx.x; i < P.n_light_f4; i += BLOCK) l_lights[i] = P.lights[i];
         __syncthreads();
         nodes = l_nodes;
         tris = l_tris;
+        mats = l_mats;
+        lights = l_lights;
     }
 
     unsigned long long lc[HJR_NSTAT];
@@ -1153,7 +1163,7 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
 
         if (tracing) {
             HitInfo prd;
-            hit_program<STATS, AOVS>(P, tris, h, ps.rd, prd, lc);
+            hit_program<STATS, AOVS>(P, tris, mats, h, ps.rd, prd, lc);
             HJR_TICKX(2)
             if (AOVS && ps.depth == 0) { sumA = sumA + prd.surf.basecolor; sumN = sumN + prd.normal; } // rt.h:191-194
             if (!prd.is_hit || prd.is_light) {
@@ -1177,7 +1187,7 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
                 if (INTEGRATOR != HJR_INTEGRATOR_PT_ && P.n_lights >= 1u) { // light_prim_count < 1: no contribution (UB in the reference)
                     float light_pdf;
                     f3 light_color, light_normal;
-                    const f3 light_position = light_sample(P, st, light_pdf, light_normal, light_color);
+                    const f3 light_position = light_sample(P, lights, st, light_pdf, light_normal, light_color);
                     if (STATS) lc[8] += 1;
                     const f3 so = prd.position;
                     f3 sd;
@@ -1227,7 +1237,7 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
                     const f3 wi = local_to_world(local_wi, t, n, b);
                     const float cosine1 = absdot(wi, n);
                     HitInfo lh;
-                    ray_trace<STATS, AOVS, WIDTH, BLOCK, ST>(P, nodes, tris, prd.position, wi, lh, stack, lc);
+                    ray_trace<STATS, AOVS, WIDTH, BLOCK, ST>(P, nodes, tris, mats, prd.position, wi, lh, stack, lc);
                     if (lh.is_hit) {
                         if (lh.is_light) {
                             const float cosine2 = absdot(-wi, lh.normal);
@@ -1239,7 +1249,7 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
                             float lp = 0.0f;
                             if (!sf.is_specular) {
                                 for (uint32_t li = 0; li < P.n_lights; li++) {
-                                    const float4* Lr = P.lights + (size_t)li * HJR_LIGHT_F4;
+                                    const float4* Lr = lights + li * HJR_LIGHT_F4;
                                     if (f2bits(Lr[4].w) == lh.prim) {
                                         const float4 a0 = Lr[0], a1 = Lr[1], a2 = Lr[2];
                                         const f3 c = cross(V(a1.x, a1.y, a1.z) - V(a0.x, a0.y, a0.z), V(a2.x, a2.y, a2.z) - V(a0.x, a0.y, a0.z));

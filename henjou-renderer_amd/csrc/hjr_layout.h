@@ -29,7 +29,7 @@
 #define HJR_BLOCK_LDS 1024          /* threads of the one-per-CU workgroup that shares an LDS copy of the BVH (16 waves = 4 per SIMD) */
 #define HJR_LDS_BUDGET (159u * 1024u)
 /* Triangle (leaf order), 48 B = 3 x float4: world-space vertices + global prim id.
- *   g0 = (v0.x v0.y v0.z v1.x)  g1 = (v1.y v1.z v2.x v2.y)  g2 = (v2.z, prim_id bits, 0, 0) */
+ *   g0 = (v0.x v0.y v0.z v1.x)  g1 = (v1.y v1.z v2.x v2.y)  g2 = (v2.z, prim_id bits, material_id bits, 0) */
 #define HJR_TRI_F4 3
 /* Shading record by GLOBAL prim id, 64 B = 4 x float4: world normals (each normalised, __closesthit__ch) + uvs + material.
  *   s0 = (n0.xyz uv0.x) s1 = (n1.xyz uv0.y) s2 = (n2.xyz uv1.x) s3 = (uv1.y uv2.x uv2.y material_id bits) */

@@ -378,17 +378,20 @@ bool build_frame(const SceneCopy& sc, const float* M, const float* Mi, uint32_t 
         float* g = &out.tri_geom[(size_t)k * 12];
         memcpy(g, &wv[9 * (size_t)t], 9 * sizeof(float));
         g[9] = u2f(t);
+        g[10] = u2f(sc.material_ids[t]); // copy of s3.w: the material fetch does not wait for the shading record
     }
     // node format: BVH2 if tree + triangles + stacks fit into the LDS of one HJR_BLOCK_LDS-thread workgroup, else BVH4
     uint32_t n_inner2 = 0;
     for (size_t i = 0; i < B.nodes.size(); i++) if (B.nodes[i].left >= 0) n_inner2++;
     if (n_inner2 == 0) n_inner2 = 1;
     const size_t bvh2_bytes = (size_t)n_inner2 * HJR_NODE2_F4 * 16 + (size_t)n * HJR_TRI_F4 * 16;
+    // the LDS variant also stages the material and light tables (hjr_kernel.hip.h): they count against the same budget
+    const size_t table_bytes = sc.materials.size() * HJR_MAT_F4 * 16 + (size_t)out.n_lights * HJR_LIGHT_F4 * 16;
     const size_t stack2 = (size_t)B.max_depth + 2;
     int lds_mode = 0;
     if (allow_lds) {
-        if ((size_t)HJR_BLOCK_LDS * stack2 * 4 + 16 + bvh2_bytes <= HJR_LDS_BUDGET) lds_mode = 1;
-        else if ((size_t)HJR_BLOCK_LDS * stack2 * 2 + 16 + bvh2_bytes <= HJR_LDS_BUDGET && n_inner2 < 32768u && n < 8192u) lds_mode = 2;
+        if ((size_t)HJR_BLOCK_LDS * stack2 * 4 + 16 + bvh2_bytes + table_bytes <= HJR_LDS_BUDGET) lds_mode = 1;
+        else if ((size_t)HJR_BLOCK_LDS * stack2 * 2 + 16 + bvh2_bytes + table_bytes <= HJR_LDS_BUDGET && n_inner2 < 32768u && n < 8192u) lds_mode = 2;
     }
     if (const char* e = getenv("HJR_BVH_WIDTH")) { // tuning knob: force a node format (forcing 4 also forces the memory path)
         int v = atoi(e);

@@ -2,6 +2,7 @@
 // Replaces the reference's CUDA/OptiX plumbing (renderer/renderer.h:197-255 upload, 293-739 context/GAS/IAS/pipeline/SBT,
 // 1175-1242 Params fill + optixLaunch).  No CPU fallback exists: without a gfx950 device every entry point fails loudly.
 #include <hip/hip_runtime.h>
+#include <chrono>
 
 #include <algorithm>
 #include <cmath>
@@ -154,7 +155,9 @@ extern "C" int hjr_set_transforms(hjr_ctx* c, const float* m, const float* inv, 
     std::string err;
     bool allow_lds = true;
     if (const char* e = getenv("HJR_LDS_BVH")) allow_lds = atoi(e) != 0;
+    const auto t_build0 = std::chrono::steady_clock::now();
     if (!hjr::build_frame(c->scene, m, inv, n, allow_lds, c->frame, err)) { set_error("hjr_set_transforms: " + err); return HJR_ERR_ARG; }
+    const double build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_build0).count();
     HIPCHK(hipSetDevice(c->device));
     const hjr::FrameData& f = c->frame;
     bool ok = c->d_nodes.upload(f.nodes.data(), f.nodes.size() * 4, c->stream) &&
@@ -167,7 +170,7 @@ extern "C" int hjr_set_transforms(hjr_ctx* c, const float* m, const float* inv, 
     c->have_frame = true;
     c->stats.bvh_nodes = f.n_nodes;
     c->stats.bvh_depth = f.depth;
-    if (getenv("HJR_VERBOSE")) fprintf(stderr, "[hjr] BVH%u (lds_mode %d): %u nodes (%zu KB), %u triangles (%zu KB), stack %u entries/lane\n", f.width, f.lds_mode, f.n_nodes, f.nodes.size() * 4 / 1024, f.n_tris, f.tri_geom.size() * 4 / 1024, f.stack_need);
+    if (getenv("HJR_VERBOSE")) fprintf(stderr, "[hjr] BVH%u (lds_mode %d): %u nodes (%zu KB), %u triangles (%zu KB), stack %u entries/lane, host build %.1f ms\n", f.width, f.lds_mode, f.n_nodes, f.nodes.size() * 4 / 1024, f.n_tris, f.tri_geom.size() * 4 / 1024, f.stack_need, build_ms);
     c->stats.n_triangles = f.n_tris;
     return HJR_OK;
 }

@@ -657,13 +657,31 @@ HD uint32_t node_step(const float4* nodes, uint32_t& cur, const BoxRay& R, float
 #endif
     } else {
     const float4* nd = nodes + cur * HJR_NODE4_F4;
+    const f3 inv = R.inv, oi = R.oi;
+    const float INF = bits2f(0x7f800000u);
+#if HJR_BVH4_QUANT
+    const float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], rr = nd[3];
+    // t = ((org + byte * scale) - o) / d  ==  byte * (scale * inv) + (org * inv + oi); near / far plane words by direction sign
+    const float ax = q0.w * inv.x, ay = q1.x * inv.y, az = q1.y * inv.z;
+    const float bx = fmaf(q0.x, inv.x, oi.x), by = fmaf(q0.y, inv.y, oi.y), bz = fmaf(q0.z, inv.z, oi.z);
+    const uint32_t nx = f2bits(R.sx ? q1.w : q1.z), fx = f2bits(R.sx ? q1.z : q1.w);
+    const uint32_t ny = f2bits(R.sy ? q2.y : q2.x), fy = f2bits(R.sy ? q2.x : q2.y);
+    const uint32_t nz = f2bits(R.sz ? q2.w : q2.z), fz = f2bits(R.sz ? q2.z : q2.w);
+#define HJR_UB(w, C) ((float)(((w) >> (8 * C)) & 0xffu))
+#define HJR_CHILD(C)                                                                                                                  \
+    float tn##C = fmaxf(fmaxf(fmaf(HJR_UB(nx, C), ax, bx), fmaf(HJR_UB(ny, C), ay, by)), fmaxf(fmaf(HJR_UB(nz, C), az, bz), tmin)); \
+    const float tf##C = fminf(fminf(fmaf(HJR_UB(fx, C), ax, bx), fmaf(HJR_UB(fy, C), ay, by)), fminf(fmaf(HJR_UB(fz, C), az, bz), tfar)); \
+    const bool h##C = tn##C <= tf##C;                                                                                                 \
+    tn##C = h##C ? tn##C : INF;
+    HJR_CHILD(0) HJR_CHILD(1) HJR_CHILD(2) HJR_CHILD(3)
+#undef HJR_CHILD
+#undef HJR_UB
+#else
     // near / far plane rows picked by the ray's direction signs: no min/max per axis
     const float4 nx = nd[0 + R.sx], fx = nd[1 - R.sx];
     const float4 ny = nd[2 + R.sy], fy = nd[3 - R.sy];
     const float4 nz = nd[4 + R.sz], fz = nd[5 - R.sz];
     const float4 rr = nd[6];
-    const f3 inv = R.inv, oi = R.oi;
-    const float INF = bits2f(0x7f800000u);
 #define HJR_CHILD(c, C)                                                                                                  \
     float tn##C = fmaxf(fmaxf(fmaf(nx.c, inv.x, oi.x), fmaf(ny.c, inv.y, oi.y)), fmaxf(fmaf(nz.c, inv.z, oi.z), tmin)); \
     const float tf##C = fminf(fminf(fmaf(fx.c, inv.x, oi.x), fmaf(fy.c, inv.y, oi.y)), fminf(fmaf(fz.c, inv.z, oi.z), tfar)); \
@@ -671,6 +689,7 @@ HD uint32_t node_step(const float4* nodes, uint32_t& cur, const BoxRay& R, float
     tn##C = h##C ? tn##C : INF;
     HJR_CHILD(x, 0) HJR_CHILD(y, 1) HJR_CHILD(z, 2) HJR_CHILD(w, 3)
 #undef HJR_CHILD
+#endif
     const uint32_t r0 = f2bits(rr.x), r1 = f2bits(rr.y), r2 = f2bits(rr.z), r3 = f2bits(rr.w);
     const float m = fminf(fminf(tn0, tn1), fminf(tn2, tn3));
     // nearest hit child first (ties: lowest slot); the other hit children are pushed in slot order
@@ -731,22 +750,27 @@ HD bool traverse(const float4* nodes, const float4* tris, f3 o, f3 d, float tmin
 // max(tripsA) + max(tripsB) — the SIMT cost of per-lane trip-count variance drops by ~1/3 (profiles/r01_experiments.md).
 // Results are identical to two separate traversals.
 //
-// Straggler carry-over (HJR_CARRY > 0): the loop also ends when at most HJR_CARRY lanes are still traversing (and at least
-// one lane of this round has finished).  Those lanes keep their traversal state (TravCarry + hit + their LDS stack column),
+// Straggler carry-over (CARRY > 0): the loop also ends when at most CARRY lanes are still traversing (and at least one
+// lane of this round has finished).  Those lanes keep their traversal state (TravCarry + hit + their LDS stack column),
 // skip the shading that follows and resume in the next round next to the other lanes' new rays: the wave's trip count per
-// round is set by the (64 - HJR_CARRY)-th slowest lane instead of the slowest one.  Per-lane results do not change.
-#ifndef HJR_CARRY
-#define HJR_CARRY 8
+// round is set by the (64 - CARRY)-th slowest lane instead of the slowest one.  Per-lane results do not change.  The
+// threshold trades traversal lane-occupancy against shading lane-occupancy (profiles/r01_experiments.md): 8 for the
+// LDS-resident scenes (shading-heavy), 32 when nodes come from memory (traversal-heavy).
+#ifndef HJR_CARRY_LDS
+#define HJR_CARRY_LDS 8
+#endif
+#ifndef HJR_CARRY_MEM
+#define HJR_CARRY_MEM 32
 #endif
 struct TravCarry { uint32_t cur; int sp, phase; };
-template <bool STATS, int WIDTH, int BLOCK, typename ST>
+template <bool STATS, int WIDTH, int BLOCK, typename ST, int CARRY>
 HD bool traverse_fused(const float4* nodes, const float4* tris, const bool a_valid, const f3 ao, const f3 ad, const float a_tmax, const bool b_valid,
                        const f3 bo, const f3 bd, bool& occluded, Hit& hit, ST* stack, Counters& ca, Counters& cb, const bool resume, TravCarry& tc)
 {
     const float tmin = 0.001f;
     int phase, sp;
     uint32_t cur;
-    if (HJR_CARRY > 0 && resume) { phase = tc.phase; sp = tc.sp; cur = tc.cur; } // occluded / hit are the caller's, kept across rounds
+    if (CARRY > 0 && resume) { phase = tc.phase; sp = tc.sp; cur = tc.cur; } // occluded / hit are the caller's, kept across rounds
     else {
         occluded = false;
         hit.prim = 0xffffffffu;
@@ -758,18 +782,16 @@ HD bool traverse_fused(const float4* nodes, const float4* tris, const bool a_val
     f3 o = (phase == 0) ? ao : bo;
     f3 d = (phase == 0) ? ad : bd;
     BoxRay R = box_ray(o, d);
-    const int n_start = HJR_CARRY > 0 ? __popcll(__ballot(phase < 2)) : 0;
+    const int n_start = CARRY > 0 ? __popcll(__ballot(phase < 2)) : 0;
 #ifdef HJR_TIMING
     unsigned long long t_node = 0, t_leaf = 0, t_last = __builtin_amdgcn_s_memtime();
 #endif
-#if HJR_CARRY > 0
     for (;;) {
-        const int n_act = __popcll(__ballot(phase < 2));
-        if (n_act == 0 || (n_act <= HJR_CARRY && n_act < n_start)) break;
+        if (CARRY > 0) {
+            const int n_act = __popcll(__ballot(phase < 2));
+            if (n_act == 0 || (n_act <= CARRY && n_act < n_start)) break;
+        } else if (__ballot(phase < 2) == 0ull) break;
         if (phase < 2) {
-#else
-    while (phase < 2) { {
-#endif
         // "while-while" traversal: every lane first descends through inner nodes until it holds a leaf (or is out of work) ...
         while (!(cur & HJR_LEAF_FLAG)) {
             const float tfar = (phase == 0) ? a_tmax : hit.t;
@@ -818,7 +840,7 @@ HD bool traverse_fused(const float4* nodes, const float4* tris, const bool a_val
 #ifdef HJR_TIMING
     ca.t_node = t_node; ca.t_leaf = t_leaf;
 #endif
-    if (HJR_CARRY > 0) { tc.phase = phase; tc.sp = sp; tc.cur = cur; return phase < 2; }
+    if (CARRY > 0) { tc.phase = phase; tc.sp = sp; tc.cur = cur; return phase < 2; }
     return false;
 }
 
@@ -1002,7 +1024,7 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
     // pending shadow ray (a regenerated path starts at the wave-uniform camera position: `fresh`); ps.L keeps the finished
     // path's radiance while fin_pending (the new path's L is 0 until that is resolved).
     bool fresh = true;          // the closest-hit ray of this lane starts at the camera
-    bool inflight = false;      // HJR_CARRY: this lane's traversal continues in the next round (it skips everything else)
+    bool inflight = false;      // carry-over: this lane's traversal continues in the next round (it skips everything else)
     bool tracing = false, occluded = false;
     Hit h;
     TravCarry tc; tc.cur = HJR_TRAV_DONE; tc.sp = 0; tc.phase = 2;
@@ -1138,7 +1160,7 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
         {
             Counters ca, cb; ca.box = ca.tri = cb.box = cb.tri = 0;
             const f3 cam_o = V(P.cam_pos[0], P.cam_pos[1], P.cam_pos[2]);
-            inflight = traverse_fused<STATS, WIDTH, BLOCK, ST>(nodes, tris, sh_valid, ps.ro, sh_d, sh_tmax, tracing, fresh ? cam_o : ps.ro, ps.rd, occluded, h, stack, ca, cb, inflight, tc);
+            inflight = traverse_fused<STATS, WIDTH, BLOCK, ST, (LDSBVH ? HJR_CARRY_LDS : HJR_CARRY_MEM)>(nodes, tris, sh_valid, ps.ro, sh_d, sh_tmax, tracing, fresh ? cam_o : ps.ro, ps.rd, occluded, h, stack, ca, cb, inflight, tc);
 #ifdef HJR_TIMING
             tk6 += ca.t_node; tk7 += ca.t_leaf;
 #endif

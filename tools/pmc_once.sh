@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$1; CNT="$2"; shift; shift
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc $CNT --output-format csv -d $OUT -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline "$@" > $OUT.log 2>&1
+timeout -k 10 240 rocprofv3 --pmc $CNT --output-format csv -d $OUT -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline "$@" > $OUT.log 2>&1
 python3 - "$OUT" <<'PY'
 import csv, collections, glob, sys
 d = collections.defaultdict(list)

@@ -1,9 +1,13 @@
 // Host half of the C-ABI (include/henjou_hip.h): scene surface, output stage and the whole-file driver
 // hjr_render_file == Renderer::initializeAndRender (renderer/renderer.h:1053-1317).
+#include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/henjou_hip.h"
@@ -200,8 +204,53 @@ extern "C" int hjr_render_file(const char* render_option_json, int device)
     }
     std::vector<float> m((size_t)view.n_instances * 12), inv((size_t)view.n_instances * 12);
     const size_t npx = (size_t)opt.image_width * opt.image_height;
-    std::vector<float> color(npx * 4), albedo(npx * 4), normal(npx * 4);
-    std::vector<uint8_t> rgba8(npx * 4);
+    // Output stage off the critical path: float4 -> sRGB8 -> PNG -> file runs on a writer thread while the main thread
+    // already builds and renders the next frame (two frame buffers in rotation).  The reference's loop is serial
+    // (renderer.h:1281-1302); the files are the same.  Only aov_color is produced: Default mode never reads the albedo /
+    // normal AOVs (they feed the OptiX denoiser, denoiser.h:94-97).  HJR_SERIAL_IO=1 disables the overlap.
+    struct Slot { std::vector<float> color; std::string name; bool full = false; };
+    Slot slots[2];
+    for (Slot& sl : slots) sl.color.resize(npx * 4);
+    std::mutex mu;
+    std::condition_variable cv;
+    bool quit = false;
+    int write_rc = HJR_OK;
+    std::string write_err;
+    const bool serial_io = getenv("HJR_SERIAL_IO") && atoi(getenv("HJR_SERIAL_IO")) != 0;
+    auto write_slot = [&](Slot& sl) -> int {
+        std::vector<uint8_t> rgba8(npx * 4);
+        hjr::float4_to_srgb8(sl.color.data(), rgba8.data(), (uint32_t)npx);
+        std::string err;
+        if (!hjr::write_png(sl.name, rgba8.data(), opt.image_width, opt.image_height, true, err)) {
+            std::lock_guard<std::mutex> lk(mu);
+            write_err = err;
+            return HJR_ERR_IO;
+        }
+        return HJR_OK;
+    };
+    std::thread writer;
+    if (!serial_io)
+        writer = std::thread([&]() {
+            int next = 0;
+            for (;;) {
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return slots[next].full || quit; });
+                    if (!slots[next].full) return; // quit with nothing pending
+                }
+                const int r = write_slot(slots[next]);
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    slots[next].full = false;
+                    if (r != HJR_OK && write_rc == HJR_OK) write_rc = r;
+                }
+                cv.notify_all();
+                next ^= 1;
+            }
+        });
+    int cur = 0;
+    const auto t_all0 = std::chrono::steady_clock::now();
+    uint32_t n_frames = 0;
     for (uint32_t frame = opt.start_frame; rc == HJR_OK && frame < opt.end_frame; frame++) {
         float time = frame / float(opt.fps); // renderer.h:1128
         hjr_scene_eval_transforms(scene, time, m.data(), inv.data());
@@ -215,18 +264,43 @@ extern "C" int hjr_render_file(const char* render_option_json, int device)
         for (int k = 0; k < 3; k++) p.sky[k] = opt.scene_sky_default[k];
         p.ibl_intensity = opt.IBL_intensity;
         p.rank = 0; p.world_size = 1;
-        rc = hjr_render(ctx, &p, color.data(), albedo.data(), normal.data());
+        Slot& sl = slots[cur];
+        if (!serial_io) { // the slot may still be with the writer (two frames behind)
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return !sl.full; });
+            if (write_rc != HJR_OK) { rc = write_rc; break; }
+        }
+        rc = hjr_render(ctx, &p, sl.color.data(), nullptr, nullptr);
         if (rc != HJR_OK) break;
         hjr_stats st;
         if (hjr_get_stats(ctx, &st) == HJR_OK)
             fprintf(stderr, "[henjou] frame %u: %ux%u, %u spp, kernel %.3f ms (%.2f Msamples/s)\n", frame, p.width, p.height, p.spp,
                     st.last_kernel_ms, st.last_kernel_ms > 0 ? (double)npx * p.spp / (st.last_kernel_ms * 1e3) : 0.0);
-        hjr_float4_to_srgb8(color.data(), rgba8.data(), (uint32_t)npx);
         std::string str_frame = std::to_string(frame); // renderer.h:1291-1302
         if (str_frame.size() < 2) str_frame = "00" + str_frame;
         else if (str_frame.size() < 3) str_frame = "0" + str_frame;
-        std::string imagename = std::string(opt.image_name) + "_" + str_frame + ".png";
-        rc = hjr_write_png(imagename.c_str(), rgba8.data(), opt.image_width, opt.image_height, 1);
+        sl.name = std::string(opt.image_name) + "_" + str_frame + ".png";
+        n_frames++;
+        if (serial_io) { rc = write_slot(sl); if (rc != HJR_OK) set_error(write_err); }
+        else {
+            { std::lock_guard<std::mutex> lk(mu); sl.full = true; }
+            cv.notify_all();
+            cur ^= 1;
+        }
+    }
+    if (!serial_io) {
+        { // drain: the writer takes the slots in order, then quits
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return !slots[0].full && !slots[1].full; });
+            quit = true;
+        }
+        cv.notify_all();
+        writer.join();
+        if (rc == HJR_OK && write_rc != HJR_OK) { rc = write_rc; set_error(write_err); }
+    }
+    if (n_frames) {
+        const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_all0).count();
+        fprintf(stderr, "[henjou] %u frame(s) in %.3f s wall (%.1f ms per frame incl. scene update, download and PNG output)\n", n_frames, wall, 1e3 * wall / n_frames);
     }
     hjr_destroy(ctx);
     hjr_scene_free(scene);

@@ -266,7 +266,7 @@ static int render_impl(hjr_ctx* c, const hjr_params* p, void* d_color, void* d_a
     if (n_items >= 0xffffffffull) { set_error("hjr_render: image too large"); return HJR_ERR_ARG; }
 
     // work area: [0] queue head, [16..] HJR_NSTAT uint64 counters
-    const size_t work_bytes = 16 + (HJR_NSTAT + 18) * 8; // +18: phase clocks / lane-occupancy sums of the HJR_TIMING diagnostic build
+    const size_t work_bytes = 16 + (HJR_NSTAT + 20) * 8; // +20: phase clocks / lane-occupancy sums of the HJR_TIMING diagnostic build
     if (c->d_work.cap < work_bytes) {
         std::vector<unsigned char> z(work_bytes, 0);
         if (!c->d_work.upload(z.data(), work_bytes, st)) { set_error("hjr_render: work buffer allocation failed"); return HJR_ERR_DEVICE; }
@@ -364,7 +364,7 @@ static int fetch_stats(hjr_ctx* c, hipStream_t st)
     for (int i = 0; i < HJR_NSTAT; i++) dst[i] = h[i];
 #ifdef HJR_TIMING
     {
-        unsigned long long tk[18];
+        unsigned long long tk[20];
         HIPCHK(hipMemcpy(tk, (char*)c->d_work.p + 16 + HJR_NSTAT * 8, sizeof(tk), hipMemcpyDeviceToHost));
         double tot = 0; for (int i = 0; i < 6; i++) tot += (double)tk[i];
         for (int i = 14; i < 18; i++) tot += (double)tk[i];
@@ -372,7 +372,8 @@ static int fetch_stats(hjr_ctx* c, hipStream_t st)
         fprintf(stderr, "[hjr timing] rr/regen %.1f%%  trace %.1f%%  resolve+hit %.1f%%  nee(light+eval) %.1f%%  bsdf sample %.1f%%  rest %.1f%%  (total %.3g wave-clocks)\n",
                 100 * tk[0] / tot, 100 * tk[1] / tot, 100 * tk[2] / tot, 100 * tk[3] / tot, 100 * tk[4] / tot, 100 * tk[5] / tot, tot);
         if (tk[8]) fprintf(stderr, "[hjr timing]   lanes per wave iteration: closest ray %.1f, shadow ray %.1f, shading %.1f (msGGX %.1f, glass %.1f); shading executed in %.0f%% of iterations\n",
-                (double)tk[9] / tk[8], (double)tk[10] / tk[8], (double)tk[11] / tk[8], (double)tk[12] / tk[8], (double)tk[13] / tk[8], 0.0);
+                (double)tk[9] / tk[8], (double)tk[10] / tk[8], (double)tk[11] / tk[8], (double)tk[12] / tk[8], (double)tk[13] / tk[8], 100.0 * tk[18] / tk[8]);
+        if (tk[18]) fprintf(stderr, "[hjr timing]   shading lanes in rounds that shade: %.1f; lanes serviced per round: %.1f\n", (double)tk[11] / tk[18], (double)tk[19] / tk[8]);
         fprintf(stderr, "[hjr timing]   inside trace: inner-node loop %.1f%%  leaf/triangles+switch %.1f%% (of total)\n", 100 * tk[6] / tot, 100 * tk[7] / tot);
     }
 #endif

@@ -1047,7 +1047,8 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
     // diagnostic build: wave-clock shares of the loop's phases, summed per wave into P.stats[10..15] (never in the shipped build)
     unsigned long long tk[6] = { 0, 0, 0, 0, 0, 0 }, tk6 = 0, tk7 = 0, tx[4] = { 0, 0, 0, 0 };
 #define HJR_TICKX(i) { __builtin_amdgcn_sched_barrier(0); unsigned long long now_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); tx[i] += now_ - tstamp; tstamp = now_; }
-    unsigned long long oc[6] = { 0, 0, 0, 0, 0, 0 }; // wave iterations, lanes tracing closest, lanes with a shadow ray, lanes shading, msGGX lanes, glass lanes
+    bool dg_shade = false, dg_ms = false, dg_glass = false;
+    unsigned long long oc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }; // wave rounds, lanes tracing closest, lanes with a shadow ray, lanes shading, msGGX lanes, glass lanes, rounds with shading, lanes serviced
     unsigned long long tstamp = __builtin_amdgcn_s_memtime();
 #define HJR_TICK(i) { __builtin_amdgcn_sched_barrier(0); unsigned long long now_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); tk[i] += now_ - tstamp; tstamp = now_; }
 #elif defined(HJR_MARK)
@@ -1100,6 +1101,13 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
             if (__ballot(!dead) == 0ull) break; // a lane only dies with nothing pending
         }
 
+#ifdef HJR_TIMING
+        { // wave-uniform occupancy sums of the previous round (all lanes are here; flags are lane-private)
+            const int n_sh = __popcll(__ballot(dg_shade));
+            oc[3] += n_sh; oc[4] += __popcll(__ballot(dg_ms)); oc[5] += __popcll(__ballot(dg_glass)); oc[6] += n_sh > 0 ? 1 : 0;
+            dg_shade = dg_ms = dg_glass = false;
+        }
+#endif
         HJR_TICKX(0)
         // NaN/Inf guard + ordered accumulation of one finished sample
         auto finish_sample = [&](f3 L) {
@@ -1170,6 +1178,9 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
             }
         }
         HJR_TICK(1)
+#ifdef HJR_TIMING
+        oc[7] += __popcll(__ballot(!inflight && (tracing || sh_valid)));
+#endif
         if (inflight) continue;
         if (sh_valid) { // `if (!light_shot.is_hit) LTE += ...` (rt.h:245-259), added to the path the shadow ray belongs to
             if (!occluded) ps.L = ps.L + sh_contrib; // ps.L is the finished path's radiance while fin_pending
@@ -1197,7 +1208,7 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
             } else {
                 HJR_TICK(2)
 #ifdef HJR_TIMING
-                oc[3] += __popcll(__ballot(true)); oc[4] += __popcll(__ballot(!prd.surf.is_specular && prd.surf.metallic > 0.5f)); oc[5] += __popcll(__ballot(prd.surf.is_specular));
+                dg_shade = true; dg_ms = !prd.surf.is_specular && prd.surf.metallic > 0.5f; dg_glass = prd.surf.is_specular;
 #endif
                 CMJState st = path_rng(P, HJR_PX, HJR_PY, s, ps.rng_depth);
                 const Surface& sf = prd.surf;
@@ -1313,7 +1324,7 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
     }
 #ifdef HJR_TIMING
     if (lane == 0) { for (int i = 0; i < 6; i++) atomicAdd(&P.stats[HJR_NSTAT + i], tk[i]); atomicAdd(&P.stats[HJR_NSTAT + 6], tk6); atomicAdd(&P.stats[HJR_NSTAT + 7], tk7); }
-    if (__ffsll((long long)__ballot(true)) - 1 == (int)lane) for (int i = 0; i < 6; i++) atomicAdd(&P.stats[HJR_NSTAT + 8 + i], oc[i]);
+    if (__ffsll((long long)__ballot(true)) - 1 == (int)lane) { for (int i = 0; i < 6; i++) atomicAdd(&P.stats[HJR_NSTAT + 8 + i], oc[i]); atomicAdd(&P.stats[HJR_NSTAT + 18], oc[6]); atomicAdd(&P.stats[HJR_NSTAT + 19], oc[7]); }
     if (lane == 0) for (int i = 0; i < 4; i++) atomicAdd(&P.stats[HJR_NSTAT + 14 + i], tx[i]);
 #endif
 

@@ -1,6 +1,11 @@
 #include "frame.hpp"
 
 #include <algorithm>
+#include <cstdio>
+#include <chrono>
+#include <atomic>
+#include <functional>
+#include <thread>
 #include <limits>
 #include <cfloat>
 #include <cmath>
@@ -57,6 +62,34 @@ bool SceneCopy::set(const hjr_scene_view& v, std::string& err)
 
 namespace {
 
+// Host worker threads for the per-frame scene preparation (flatten, BVH build, emit).  Every parallel loop below is either
+// element-wise or merges per-chunk partial results that are exact (min / max / integer counts), so the emitted arrays do not
+// depend on the thread count.  HJR_HOST_THREADS overrides the default min(hardware threads, 16).
+inline unsigned host_threads()
+{
+    static const unsigned n = [] {
+        if (const char* e = getenv("HJR_HOST_THREADS")) { int v = atoi(e); if (v >= 1) return (unsigned)std::min(v, 256); }
+        unsigned h = std::thread::hardware_concurrency();
+        return h == 0 ? 1u : std::min(h, 16u);
+    }();
+    return n;
+}
+// f(begin, end, chunk): [0, n) cut into `chunks` equal ranges (a pure function of n and grain), run on host_threads() threads
+template <class F> void parallel_chunks(size_t n, size_t grain, F f)
+{
+    const size_t chunks = std::max<size_t>(1, std::min<size_t>(64, n / std::max<size_t>(grain, 1)));
+    auto range = [&](size_t c, size_t& b, size_t& e) { b = n * c / chunks; e = n * (c + 1) / chunks; };
+    const unsigned T = (unsigned)std::min<size_t>(host_threads(), chunks);
+    if (T <= 1) { for (size_t c = 0; c < chunks; c++) { size_t b, e; range(c, b, e); f(b, e, c); } return; }
+    std::atomic<size_t> next(0);
+    auto work = [&] { for (;;) { size_t c = next.fetch_add(1); if (c >= chunks) return; size_t b, e; range(c, b, e); f(b, e, c); } };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < T; t++) th.emplace_back(work);
+    work();
+    for (auto& t : th) t.join();
+}
+inline size_t n_chunks_of(size_t n, size_t grain) { return std::max<size_t>(1, std::min<size_t>(64, n / std::max<size_t>(grain, 1))); }
+
 struct V3 { float x, y, z; };
 inline V3 sub(V3 a, V3 b) { return { a.x - b.x, a.y - b.y, a.z - b.z }; }
 inline float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
@@ -93,21 +126,39 @@ struct Box {
 
 struct BuildNode { Box box; int left = -1, right = -1; uint32_t first = 0, count = 0; };
 
+struct BuildTask { int node; uint32_t first, count, depth; };
+
 struct Builder {
     uint32_t leaf_max = HJR_LEAF_DEFAULT;
-    std::vector<Box> tbox;
-    std::vector<float> cent; // 3 per tri
-    std::vector<uint32_t> order;
+    const Box* tbox = nullptr;   // per triangle (padded)
+    const float* cent = nullptr; // 3 per triangle
+    uint32_t* order = nullptr;   // permutation being partitioned in place (subtrees own disjoint ranges)
     std::vector<BuildNode> nodes;
     uint32_t max_depth = 0;
+    // Large scenes: subtrees of at most `defer_below` triangles are not built by the top-level recursion but recorded as tasks
+    // (their root node is a placeholder) and built afterwards by worker threads, each into its own node array (build_parallel).
+    uint32_t defer_below = 0;
+    std::vector<BuildTask> tasks;
 
     int build(uint32_t first, uint32_t count, uint32_t depth)
     {
         int me = (int)nodes.size();
         nodes.emplace_back();
+        if (defer_below && depth > 0 && count <= defer_below) { tasks.push_back({ me, first, count, depth }); return me; }
+        const bool big = count >= 65536u; // worth a parallel pass
         Box bb, cb;
         bb.reset(); cb.reset();
-        for (uint32_t i = first; i < first + count; i++) { bb.grow(tbox[order[i]]); cb.grow(&cent[3 * order[i]]); }
+        if (big) {
+            const size_t nc = n_chunks_of(count, 16384);
+            std::vector<Box> pb(nc), pc(nc);
+            parallel_chunks(count, 16384, [&](size_t b0, size_t e0, size_t c) {
+                Box x, y; x.reset(); y.reset();
+                for (size_t i = first + b0; i < first + e0; i++) { x.grow(tbox[order[i]]); y.grow(&cent[3 * (size_t)order[i]]); }
+                pb[c] = x; pc[c] = y;
+            });
+            for (size_t c = 0; c < nc; c++) { bb.grow(pb[c]); cb.grow(pc[c]); }
+        } else
+            for (uint32_t i = first; i < first + count; i++) { bb.grow(tbox[order[i]]); cb.grow(&cent[3 * (size_t)order[i]]); }
         nodes[me].box = bb;
         max_depth = std::max(max_depth, depth);
         if (count <= leaf_max && (count <= 1 || depth > 0)) { // the root is always split so that it is an inner node
@@ -123,23 +174,37 @@ struct Builder {
         if (!force_median) {
             const int NB = 16;
             float best = FLT_MAX; int bax = -1, bsp = -1;
+            struct Bins { Box box[16]; uint32_t cnt[16]; };
             for (int ax = 0; ax < 3; ax++) {
                 float c0 = cb.lo[ax], c1 = cb.hi[ax];
                 if (!(c1 > c0)) continue;
-                Box bins[NB]; uint32_t cnt[NB];
-                for (int b = 0; b < NB; b++) { bins[b].reset(); cnt[b] = 0; }
+                Bins bins;
+                for (int b = 0; b < NB; b++) { bins.box[b].reset(); bins.cnt[b] = 0; }
                 float scale = (float)NB / (c1 - c0);
-                for (uint32_t i = first; i < first + count; i++) {
-                    int b = (int)((cent[3 * order[i] + ax] - c0) * scale);
-                    b = b < 0 ? 0 : (b >= NB ? NB - 1 : b);
-                    bins[b].grow(tbox[order[i]]); cnt[b]++;
-                }
+                auto fill = [&](Bins& B, size_t i0, size_t i1) {
+                    for (size_t i = i0; i < i1; i++) {
+                        int b = (int)((cent[3 * (size_t)order[i] + ax] - c0) * scale);
+                        b = b < 0 ? 0 : (b >= NB ? NB - 1 : b);
+                        B.box[b].grow(tbox[order[i]]); B.cnt[b]++;
+                    }
+                };
+                if (big) {
+                    const size_t nc = n_chunks_of(count, 16384);
+                    std::vector<Bins> part(nc);
+                    parallel_chunks(count, 16384, [&](size_t b0, size_t e0, size_t c) {
+                        Bins& P = part[c];
+                        for (int b = 0; b < NB; b++) { P.box[b].reset(); P.cnt[b] = 0; }
+                        fill(P, first + b0, first + e0);
+                    });
+                    for (size_t c = 0; c < nc; c++)
+                        for (int b = 0; b < NB; b++) { bins.box[b].grow(part[c].box[b]); bins.cnt[b] += part[c].cnt[b]; }
+                } else fill(bins, first, (size_t)first + count);
                 float rarea[NB]; uint32_t rcnt[NB];
                 Box acc; acc.reset(); uint32_t n = 0;
-                for (int b = NB - 1; b > 0; b--) { acc.grow(bins[b]); n += cnt[b]; rarea[b] = acc.area(); rcnt[b] = n; }
+                for (int b = NB - 1; b > 0; b--) { acc.grow(bins.box[b]); n += bins.cnt[b]; rarea[b] = acc.area(); rcnt[b] = n; }
                 acc.reset(); n = 0;
                 for (int b = 0; b < NB - 1; b++) {
-                    acc.grow(bins[b]); n += cnt[b];
+                    acc.grow(bins.box[b]); n += bins.cnt[b];
                     if (n == 0 || rcnt[b + 1] == 0) continue;
                     float cost = acc.area() * (float)n + rarea[b + 1] * (float)rcnt[b + 1];
                     if (cost < best) { best = cost; bax = ax; bsp = b; }
@@ -148,12 +213,12 @@ struct Builder {
             if (bax >= 0) {
                 float c0 = cb.lo[bax], c1 = cb.hi[bax];
                 float scale = 16.0f / (c1 - c0);
-                auto it = std::partition(order.begin() + first, order.begin() + first + count, [&](uint32_t t) {
-                    int b = (int)((cent[3 * t + bax] - c0) * scale);
+                uint32_t* it = std::partition(order + first, order + first + count, [&](uint32_t t) {
+                    int b = (int)((cent[3 * (size_t)t + bax] - c0) * scale);
                     b = b < 0 ? 0 : (b >= 16 ? 15 : b);
                     return b <= bsp;
                 });
-                mid = (uint32_t)(it - order.begin());
+                mid = (uint32_t)(it - order);
                 have = mid > first && mid < first + count;
             }
         }
@@ -162,13 +227,56 @@ struct Builder {
             float ext = cb.hi[0] - cb.lo[0];
             for (int a = 1; a < 3; a++) if (cb.hi[a] - cb.lo[a] > ext) { ext = cb.hi[a] - cb.lo[a]; ax = a; }
             mid = first + count / 2;
-            std::nth_element(order.begin() + first, order.begin() + mid, order.begin() + first + count,
-                             [&](uint32_t a, uint32_t b) { return cent[3 * a + ax] < cent[3 * b + ax] || (cent[3 * a + ax] == cent[3 * b + ax] && a < b); });
+            std::nth_element(order + first, order + mid, order + first + count,
+                             [&](uint32_t a, uint32_t b) { return cent[3 * (size_t)a + ax] < cent[3 * (size_t)b + ax] || (cent[3 * (size_t)a + ax] == cent[3 * (size_t)b + ax] && a < b); });
         }
         int l = build(first, mid - first, depth + 1);
         int r = build(mid, first + count - mid, depth + 1);
         nodes[me].left = l; nodes[me].right = r;
         return me;
+    }
+
+    // Whole tree.  Scenes below `par_min` triangles: the plain recursion.  Above: the top of the tree is built by this thread
+    // (its big nodes with parallel passes), the subtrees by worker threads; sub-results are spliced in task order, so the node
+    // array (and everything emitted from it) is the same for any number of threads.
+    void build_all(uint32_t n, uint32_t par_min = 65536u, uint32_t task_size = 32768u)
+    {
+        nodes.reserve((size_t)2 * n);
+        if (n < par_min) { build(0, n, 0); return; }
+        const bool timing = getenv("HJR_BUILD_TIMING") != nullptr;
+        auto t0 = std::chrono::steady_clock::now();
+        defer_below = task_size;
+        build(0, n, 0);
+        defer_below = 0;
+        if (timing) fprintf(stderr, "[hjr build]   top of the tree: %.1f ms, %zu subtree tasks, %u threads\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), tasks.size(), host_threads());
+        std::vector<Builder> sub(tasks.size());
+        parallel_chunks(tasks.size(), 1, [&](size_t b0, size_t e0, size_t) {
+            for (size_t k = b0; k < e0; k++) {
+                Builder& S = sub[k];
+                S.leaf_max = leaf_max; S.tbox = tbox; S.cent = cent; S.order = order;
+                S.nodes.reserve((size_t)2 * tasks[k].count);
+                S.build(tasks[k].first, tasks[k].count, tasks[k].depth); // depth > 0: the sub-root may be a leaf
+            }
+        });
+        if (timing) fprintf(stderr, "[hjr build]   + subtrees: %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+        // splice in task order: the sub-root replaces its placeholder, the other sub-nodes are appended (local i > 0 -> base + i)
+        std::vector<size_t> base(tasks.size());
+        size_t total = nodes.size();
+        for (size_t k = 0; k < tasks.size(); k++) { base[k] = total - 1; total += sub[k].nodes.size() - 1; max_depth = std::max(max_depth, sub[k].max_depth); }
+        nodes.resize(total);
+        parallel_chunks(tasks.size(), 1, [&](size_t b0, size_t e0, size_t) {
+            for (size_t k = b0; k < e0; k++) {
+                const Builder& S = sub[k];
+                auto remap = [&](int i) { return i < 0 ? i : (i == 0 ? tasks[k].node : (int)(base[k] + (size_t)i)); };
+                for (size_t i = 0; i < S.nodes.size(); i++) {
+                    BuildNode nd = S.nodes[i];
+                    nd.left = remap(nd.left); nd.right = remap(nd.right);
+                    nodes[i == 0 ? (size_t)tasks[k].node : base[k] + i] = nd;
+                }
+            }
+        });
+        tasks.clear();
+        if (timing) fprintf(stderr, "[hjr build]   + splice: %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     }
 };
 
@@ -288,7 +396,8 @@ void emit_bvh4(const Builder& B, FrameData& out)
         }
     }
 #else
-    for (size_t i = 0; i < wide.size(); i++) {
+    parallel_chunks(wide.size(), 8192, [&](size_t ib, size_t ie, size_t) {
+    for (size_t i = ib; i < ie; i++) {
         float* q = &out.nodes[i * (size_t)HJR_NODE4_F4 * 4];
         for (int c = 0; c < 4; c++) {
             if (c < wide[i].n) {
@@ -301,6 +410,7 @@ void emit_bvh4(const Builder& B, FrameData& out)
             }
         }
     }
+    });
 #endif
     // exact worst-case traversal stack: every visited wide node can leave (children - 1) entries pending
     std::vector<uint32_t> pend(wide.size(), 0);
@@ -322,6 +432,14 @@ bool build_frame(const SceneCopy& sc, const float* M, const float* Mi, uint32_t 
 {
     if (n_inst != sc.n_instances) { err = "instance count does not match the uploaded scene"; return false; }
     const uint32_t n = sc.n_triangles;
+    const bool timing = getenv("HJR_BUILD_TIMING") != nullptr; // stage times on stderr
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[hjr build] %-22s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     out = FrameData();
     out.n_tris = n;
     out.tri_shade.assign((size_t)n * HJR_SHADE_F4 * 4, 0.0f);
@@ -329,18 +447,20 @@ bool build_frame(const SceneCopy& sc, const float* M, const float* Mi, uint32_t 
     std::vector<float> wv((size_t)n * 9);
 
     // __closesthit__ch's per-hit work, done once per triangle (stale ptx:900-1263)
-    for (uint32_t i = 0; i < n_inst; i++) {
-        uint32_t t0 = sc.prim_offset[i], t1 = (i + 1 < n_inst) ? sc.prim_offset[i + 1] : n;
-        const float* m = M + 12 * i;
-        const float* mi = Mi + 12 * i;
-        for (uint32_t t = t0; t < t1; t++) {
-            float* s = &out.tri_shade[(size_t)t * 16];
+    parallel_chunks(n, 16384, [&](size_t tb, size_t te, size_t) {
+        // instance of triangle tb: last prim_offset <= tb (empty instances share an offset with their successor)
+        uint32_t i = (uint32_t)(std::upper_bound(sc.prim_offset.begin(), sc.prim_offset.begin() + n_inst, (uint32_t)tb) - sc.prim_offset.begin()) - 1;
+        for (size_t t = tb; t < te; t++) {
+            while (i + 1 < n_inst && sc.prim_offset[i + 1] <= t) i++;
+            const float* m = M + 12 * (size_t)i;
+            const float* mi = Mi + 12 * (size_t)i;
+            float* s = &out.tri_shade[t * 16];
             float uv[6];
             for (int k = 0; k < 3; k++) {
                 uint32_t idx = sc.indices[3 * t + k];
                 V3 v = transform_position(m, { sc.vertices[3 * idx], sc.vertices[3 * idx + 1], sc.vertices[3 * idx + 2] });
                 V3 nn = normalize(transform_normal(mi, { sc.normals[3 * idx], sc.normals[3 * idx + 1], sc.normals[3 * idx + 2] }));
-                wv[9 * (size_t)t + 3 * k + 0] = v.x; wv[9 * (size_t)t + 3 * k + 1] = v.y; wv[9 * (size_t)t + 3 * k + 2] = v.z;
+                wv[9 * t + 3 * k + 0] = v.x; wv[9 * t + 3 * k + 1] = v.y; wv[9 * t + 3 * k + 2] = v.z;
                 s[4 * k + 0] = nn.x; s[4 * k + 1] = nn.y; s[4 * k + 2] = nn.z;
                 uv[2 * k] = sc.texcoords[2 * idx]; uv[2 * k + 1] = sc.texcoords[2 * idx + 1];
             }
@@ -349,8 +469,9 @@ bool build_frame(const SceneCopy& sc, const float* M, const float* Mi, uint32_t 
             s[15] = u2f(sc.material_ids[t]);
             out.tri_inst[t] = i;
         }
-    }
+    });
 
+    lap("flatten");
     // light table (light_sample.h:22-58, 69-72)
     const uint32_t nl = (uint32_t)sc.light_prim_ids.size();
     out.n_lights = nl;
@@ -385,22 +506,36 @@ bool build_frame(const SceneCopy& sc, const float* M, const float* Mi, uint32_t 
     // BVH over padded triangle boxes
     Builder B;
     if (const char* e = getenv("HJR_LEAF_MAX")) { int v = atoi(e); if (v >= 1 && v <= (int)HJR_LEAF_MAX) B.leaf_max = (uint32_t)v; } // tuning knob
-    B.tbox.resize(n); B.cent.resize((size_t)n * 3); B.order.resize(n);
+    std::vector<Box> tbox(n);
+    std::vector<float> cent((size_t)n * 3);
+    std::vector<uint32_t> order(n);
     float smax = 0.0f;
-    for (uint32_t t = 0; t < n; t++) {
-        Box b; b.reset();
-        for (int k = 0; k < 3; k++) b.grow(&wv[9 * (size_t)t + 3 * k]);
-        for (int a = 0; a < 3; a++) {
-            B.cent[3 * (size_t)t + a] = 0.5f * (b.lo[a] + b.hi[a]);
-            smax = std::max(smax, std::max(fabsf(b.lo[a]), fabsf(b.hi[a])));
-        }
-        B.tbox[t] = b; B.order[t] = t;
+    {
+        std::vector<float> part(n_chunks_of(n, 16384), 0.0f);
+        parallel_chunks(n, 16384, [&](size_t tb, size_t te, size_t c) {
+            float mx = 0.0f;
+            for (size_t t = tb; t < te; t++) {
+                Box b; b.reset();
+                for (int k = 0; k < 3; k++) b.grow(&wv[9 * t + 3 * k]);
+                for (int a = 0; a < 3; a++) {
+                    cent[3 * t + a] = 0.5f * (b.lo[a] + b.hi[a]);
+                    mx = std::max(mx, std::max(fabsf(b.lo[a]), fabsf(b.hi[a])));
+                }
+                tbox[t] = b; order[t] = (uint32_t)t;
+            }
+            part[c] = mx;
+        });
+        for (float v : part) { if (!(v <= smax)) smax = v; } // a NaN partial maximum must surface too
     }
     if (!(smax < 1e30f)) { err = "non-finite vertex after transform"; return false; }
     // conservative padding: the slab test must never cull a triangle the canonical ray/triangle test accepts
     float pad = smax * (1.0f / 32768.0f);
-    for (uint32_t t = 0; t < n; t++)
-        for (int a = 0; a < 3; a++) { B.tbox[t].lo[a] -= pad; B.tbox[t].hi[a] += pad; }
+    parallel_chunks(n, 65536, [&](size_t tb, size_t te, size_t) {
+        for (size_t t = tb; t < te; t++)
+            for (int a = 0; a < 3; a++) { tbox[t].lo[a] -= pad; tbox[t].hi[a] += pad; }
+    });
+    B.tbox = tbox.data(); B.cent = cent.data(); B.order = order.data();
+    lap("boxes");
 
     out.tri_geom.assign((size_t)std::max(n, 1u) * HJR_TRI_F4 * 4, 0.0f);
     if (n == 0) { // empty scene: one BVH4 root with four empty slots
@@ -419,17 +554,20 @@ bool build_frame(const SceneCopy& sc, const float* M, const float* Mi, uint32_t 
         out.stack_need = 2;
         return true;
     }
-    B.nodes.reserve((size_t)2 * n);
-    B.build(0, n, 0);
+    B.build_all(n);
+    lap("bvh2 build");
     if (B.max_depth >= HJR_STACK_DEPTH) { err = "BVH deeper than the traversal stack"; return false; }
     out.depth = B.max_depth;
-    for (uint32_t k = 0; k < n; k++) {
-        uint32_t t = B.order[k];
-        float* g = &out.tri_geom[(size_t)k * 12];
-        memcpy(g, &wv[9 * (size_t)t], 9 * sizeof(float));
-        g[9] = u2f(t);
-        g[10] = u2f(sc.material_ids[t]); // copy of s3.w: the material fetch does not wait for the shading record
-    }
+    parallel_chunks(n, 65536, [&](size_t kb, size_t ke, size_t) {
+        for (size_t k = kb; k < ke; k++) {
+            uint32_t t = order[k];
+            float* g = &out.tri_geom[k * 12];
+            memcpy(g, &wv[9 * (size_t)t], 9 * sizeof(float));
+            g[9] = u2f(t);
+            g[10] = u2f(sc.material_ids[t]); // copy of s3.w: the material fetch does not wait for the shading record
+        }
+    });
+    lap("triangle reorder");
     // node format: BVH2 if tree + triangles + stacks fit into the LDS of one HJR_BLOCK_LDS-thread workgroup, else BVH4
     uint32_t n_inner2 = 0;
     for (size_t i = 0; i < B.nodes.size(); i++) if (B.nodes[i].left >= 0) n_inner2++;
@@ -451,6 +589,7 @@ bool build_frame(const SceneCopy& sc, const float* M, const float* Mi, uint32_t 
     out.lds_mode = lds_mode;
     if (out.width == 2) emit_bvh2(B, out);
     else emit_bvh4(B, out);
+    lap("emit nodes");
     return true;
 }
 

@@ -178,6 +178,22 @@ def main():
                 traffic = json.load(open(tpath)).get("%s_%dx%dx%d_%s_n%d" % (args.scene, W, H, SPP, args.integrator, world))
             except Exception:
                 traffic = None
+        # next to the algorithmic-bytes fraction, the measured HBM rate and the VALU issue load (the binding limit of
+        # the LDS-resident scene) from the committed rocprofv3 PMC passes of this exact workload, scaled by the live kernel time
+        side = None
+        try:
+            prof = json.load(open(tpath))
+            key = "%s_%dx%dx%d_%s_n%d" % (args.scene, W, H, SPP, args.integrator, world)
+            if traffic is not None and (key + "_valu_insts") in prof:
+                valu = float(prof[key + "_valu_insts"])
+                clk = float(prof[key + "_gui_active_cycles_x8"]) / 8.0  # shader-clock cycles of the profiled launch
+                side = {"hbm_measured_GBps": round(traffic / (avg_ms * 1e-3) / 1e9, 2),
+                        "hbm_measured_frac": round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
+                        "valu_wave_insts_per_launch": valu,
+                        "simd_cycles_per_valu_inst": round(clk * 1024.0 / valu, 3),
+                        "note": "256 CUs x 4 SIMDs; measured issue cost 2.6 (v_xor) .. 3.9 (v_fma_f32) .. 8.3 (v_rcp/v_sqrt) cycles per wave-instruction (tools/ubench/valu_rate.hip): VALU issue is the binding limit, HBM is idle"}
+        except Exception:
+            side = None
         out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                            "kernel": "hjr_render_kernel<%s>" % args.integrator, "kernel_ms_avg": round(avg_ms, 3),
@@ -186,6 +202,8 @@ def main():
                                           ("closest_rays", "shadow_rays", "box_tests_closest", "tri_tests_closest",
                                            "box_tests_shadow", "tri_tests_shadow", "shaded_hits", "light_samples")},
                            "kernel_Msamples_per_s": round(samples_per_launch / (avg_ms * 1e-3) / 1e6, 3)}
+        if side:
+            out["roofline"]["side_by_side"] = side
 
         # ---- CPU baseline: the oracle (kind "port": the reference has no CPU path), bounded sample
         if world == 1 and not args.no_cpu_baseline:

@@ -54,6 +54,7 @@ struct hjr_ctx {
     int lut_w = 0, lut_h = 0;
     DevBuf d_color, d_albedo, d_normal; // staging for hjr_render (host buffers)
     DevBuf d_part_color, d_part_albedo, d_part_normal; // chunk sums [n_chunks][H][W] float4
+    DevBuf d_spill; // overflow of the short traversal stacks (memory-path kernels)
     hjr_stats stats;
     bool event_pending = false;
     int blocks_per_cu = 0; // 0 = ask the occupancy API
@@ -106,7 +107,7 @@ extern "C" void hjr_destroy(hjr_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    for (DevBuf* b : { &c->d_nodes, &c->d_tri_geom, &c->d_tri_shade, &c->d_tri_inst, &c->d_materials, &c->d_lights, &c->d_lut,
+    for (DevBuf* b : { &c->d_nodes, &c->d_tri_geom, &c->d_tri_shade, &c->d_tri_inst, &c->d_materials, &c->d_lights, &c->d_lut, &c->d_spill,
                        &c->d_texels, &c->d_tex_desc, &c->d_srgb_lut, &c->d_sky, &c->d_work, &c->d_color, &c->d_albedo, &c->d_normal, &c->d_part_color, &c->d_part_albedo, &c->d_part_normal })
         b->release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -200,10 +201,10 @@ extern "C" int hjr_set_sky(hjr_ctx* c, const float* rgba, int w, int h)
     return HJR_OK;
 }
 
-template <int I, bool S, int W> static int launch_mem(const hjr_ctx* c, const KParams& kp, uint64_t n_items, hipStream_t st);
-template <int I, bool S, int W, bool A> static int launch_mem2(const hjr_ctx* c, const KParams& kp, uint64_t n_items, hipStream_t st);
+template <int I, bool S, int W> static int launch_mem(hjr_ctx* c, const KParams& kp, uint64_t n_items, hipStream_t st);
+template <int I, bool S, int W, bool A> static int launch_mem2(hjr_ctx* c, const KParams& kp, uint64_t n_items, hipStream_t st);
 // lds_mode: 0 = BVH4 read from memory, 1 = BVH2 staged in LDS with 32-bit stack entries, 2 = with 16-bit entries, 3 = BVH2 from memory
-template <int I, bool S, bool S16, bool A> static int launch_lds2(const hjr_ctx* c, const KParams& kp, uint64_t n_items, hipStream_t st)
+template <int I, bool S, bool S16, bool A> static int launch_lds2(hjr_ctx* c, const KParams& kp, uint64_t n_items, hipStream_t st)
 {
     const size_t smem = (((size_t)HJR_BLOCK_LDS * kp.stack_depth * (S16 ? 2 : 4) + 15) / 16) * 16 + ((size_t)kp.n_node_f4 + kp.n_tri_f4 + kp.n_mat_f4 + kp.n_light_f4) * 16;
     auto kern = hjr_render_kernel<I, S, HJR_BLOCK_LDS, true, S16, 2, A>;
@@ -215,26 +216,27 @@ template <int I, bool S, bool S16, bool A> static int launch_lds2(const hjr_ctx*
     return 0;
 }
 // the albedo / normal AOV sums cost 6 VGPRs per lane: a separate instantiation for callers that only want aov_color
-template <int I, bool S, bool S16> static int launch_lds(const hjr_ctx* c, const KParams& kp, uint64_t n_items, hipStream_t st)
+template <int I, bool S, bool S16> static int launch_lds(hjr_ctx* c, const KParams& kp, uint64_t n_items, hipStream_t st)
 {
     const bool full = kp.aov_albedo || kp.aov_normal || kp.tex_desc || kp.sky_tex;
     return full ? launch_lds2<I, S, S16, true>(c, kp, n_items, st) : launch_lds2<I, S, S16, false>(c, kp, n_items, st);
 }
-template <int I, bool S> static int launch(const hjr_ctx* c, const KParams& kp, uint64_t n_items, int lds_mode, hipStream_t st)
+template <int I, bool S> static int launch(hjr_ctx* c, const KParams& kp, uint64_t n_items, int lds_mode, hipStream_t st)
 {
     if (lds_mode == 1) return launch_lds<I, S, false>(c, kp, n_items, st);
     if (lds_mode == 2) return launch_lds<I, S, true>(c, kp, n_items, st);
     if (lds_mode == 3) return launch_mem<I, S, 2>(c, kp, n_items, st); // BVH2 read from memory (HJR_BVH_WIDTH=2 knob on a big scene)
     return launch_mem<I, S, 4>(c, kp, n_items, st);
 }
-template <int I, bool S, int W> static int launch_mem(const hjr_ctx* c, const KParams& kp, uint64_t n_items, hipStream_t st)
+template <int I, bool S, int W> static int launch_mem(hjr_ctx* c, const KParams& kp, uint64_t n_items, hipStream_t st)
 {
     const bool full = kp.aov_albedo || kp.aov_normal || kp.tex_desc || kp.sky_tex;
     return full ? launch_mem2<I, S, W, true>(c, kp, n_items, st) : launch_mem2<I, S, W, false>(c, kp, n_items, st);
 }
-template <int I, bool S, int W, bool A> static int launch_mem2(const hjr_ctx* c, const KParams& kp, uint64_t n_items, hipStream_t st)
+template <int I, bool S, int W, bool A> static int launch_mem2(hjr_ctx* c, const KParams& kp, uint64_t n_items, hipStream_t st)
 {
-    const size_t smem = (size_t)HJR_BLOCK * kp.stack_depth * 4;
+    const uint32_t lds_entries = kp.stack_depth < (uint32_t)HJR_SHORT_STACK ? kp.stack_depth : (uint32_t)HJR_SHORT_STACK;
+    const size_t smem = (size_t)HJR_BLOCK * lds_entries * 4;
     auto kern = hjr_render_kernel<I, S, HJR_BLOCK, false, false, W, A>;
     int per_cu = 0;
     if (c->blocks_per_cu > 0) per_cu = c->blocks_per_cu;
@@ -243,7 +245,17 @@ template <int I, bool S, int W, bool A> static int launch_mem2(const hjr_ctx* c,
     uint64_t blocks = (uint64_t)c->n_cus * (uint64_t)per_cu;
     uint64_t max_useful = (n_items + HJR_BLOCK - 1) / HJR_BLOCK;
     if (blocks > max_useful) blocks = max_useful ? max_useful : 1;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(HJR_BLOCK), smem, st, kp);
+    KParams k2 = kp;
+    k2.spill_stride = (uint32_t)(blocks * HJR_BLOCK);
+    const uint32_t over = kp.stack_depth > lds_entries ? kp.stack_depth - lds_entries : 0u;
+    const size_t spill_bytes = (size_t)k2.spill_stride * (over ? over : 1u) * 4;
+    if (c->d_spill.cap < spill_bytes) {
+        c->d_spill.release();
+        if (hipMalloc(&c->d_spill.p, spill_bytes) != hipSuccess) return -1;
+        c->d_spill.cap = spill_bytes;
+    }
+    k2.stack_spill = (uint32_t*)c->d_spill.p;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(HJR_BLOCK), smem, st, k2);
     return 0;
 }
 

@@ -46,6 +46,8 @@ struct KParams {
     uint32_t n_node_f4, n_tri_f4;    // float4 counts of nodes[] / tri_geom[] (LDS staging)
     uint32_t n_mat_f4, n_light_f4;   // float4 counts of materials[] / lights[] (staged behind the triangles in the LDS variant)
     uint32_t stack_depth;            // traversal stack entries per lane (BVH depth + 1)
+    uint32_t* stack_spill;           // memory-path kernels: overflow of the short LDS stacks, [level][lane]
+    uint32_t spill_stride;           // lanes in the grid
     float4* part_color;              // [n_chunks][height][width] chunk sums when n_chunks > 1
     float4* part_albedo;
     float4* part_normal;
@@ -587,6 +589,31 @@ HD uint32_t stack_dec(uint16_t r16)
     return (r & 0x8000u) ? (HJR_LEAF_FLAG | (((r >> 13) & 3u) << 27) | (r & 0x1fffu)) : r;
 }
 
+// One lane's traversal stack.  SHORT == 0: every entry in LDS (column of this lane).  SHORT > 0 (kernels that read the BVH from
+// memory): only the top-of-tree SHORT entries are in LDS, deeper ones overflow into a per-lane column of a global buffer
+// ([level][lane], coalesced when neighbouring lanes overflow together).  The exact worst-case depth of a BVH4 over a million
+// triangles is ~46 entries, traversal rarely needs more than a dozen: with the whole stack in LDS the stacks, not the
+// registers, capped the occupancy at 3 workgroups per CU.
+#ifndef HJR_SHORT_STACK
+#define HJR_SHORT_STACK 16
+#endif
+template <typename E, int BLOCK_, int SHORT>
+struct LaneStack {
+    E* lds;
+    uint32_t* spill;
+    uint32_t spill_stride;
+    HD void put(int i, uint32_t ref)
+    {
+        if (SHORT == 0 || i < SHORT) lds[i * BLOCK_] = stack_enc<E>(ref);
+        else spill[(size_t)(i - SHORT) * spill_stride] = ref;
+    }
+    HD uint32_t get(int i) const
+    {
+        if (SHORT == 0 || i < SHORT) return stack_dec(lds[i * BLOCK_]);
+        return spill[(size_t)(i - SHORT) * spill_stride];
+    }
+};
+
 // ---- box-test side of a ray.  The slab test only has to be conservative (boxes are padded): it uses the
 // 1-ulp hardware reciprocal and (plane - o) * inv evaluated as fma(plane, inv, -o * inv).  Direction components smaller than
 // 1e-30 are clamped (sign kept) so that inv stays finite and no inf - inf can appear for axis-parallel rays.
@@ -609,7 +636,7 @@ HD BoxRay box_ray(f3 o, f3 d)
 // One inner-node step: tests the children of node `cur` against [tmin, tfar], continues with the nearest hit child, pushes
 // the other hit children, or pops (HJR_TRAV_DONE when the stack is empty).  Returns the number of boxes tested.
 template <int WIDTH, int BLOCK, typename ST>
-HD uint32_t node_step(const float4* nodes, uint32_t& cur, const BoxRay& R, float tmin, float tfar, ST* stack, int& sp)
+HD uint32_t node_step(const float4* nodes, uint32_t& cur, const BoxRay& R, float tmin, float tfar, ST& stack, int& sp)
 {
     if constexpr (WIDTH == 2) {
     const float4* nd = nodes + cur * HJR_NODE2_F4;
@@ -635,23 +662,23 @@ HD uint32_t node_step(const float4* nodes, uint32_t& cur, const BoxRay& R, float
     const bool both = h0 & h1, any = h0 | h1;
     const bool swap = lo1 < lo0;
     const uint32_t nearc = both ? (swap ? c1 : c0) : (h0 ? c0 : c1);
-    if (both) stack[sp * BLOCK] = stack_enc<ST>(swap ? c0 : c1);
+    if (both) stack.put(sp, swap ? c0 : c1);
     sp += both ? 1 : 0;
     uint32_t popped = HJR_TRAV_DONE;
     const bool do_pop = !any & (sp > 0);
-    if (do_pop) popped = stack_dec(stack[(sp - 1) * BLOCK]);
+    if (do_pop) popped = stack.get(sp - 1);
     sp -= do_pop ? 1 : 0;
     cur = any ? nearc : popped;
     return 2u;
 #else
     if (h0 && h1) {
         const bool swap = lo1 < lo0;
-        stack[sp * BLOCK] = stack_enc<ST>(swap ? c0 : c1);
+        stack.put(sp, swap ? c0 : c1);
         sp++;
         cur = swap ? c1 : c0;
     } else if (h0) cur = c0;
     else if (h1) cur = c1;
-    else if (sp > 0) { sp--; cur = stack_dec(stack[sp * BLOCK]); }
+    else if (sp > 0) { sp--; cur = stack.get(sp); }
     else cur = HJR_TRAV_DONE;
     return 2u;
 #endif
@@ -694,12 +721,12 @@ HD uint32_t node_step(const float4* nodes, uint32_t& cur, const BoxRay& R, float
     const float m = fminf(fminf(tn0, tn1), fminf(tn2, tn3));
     // nearest hit child first (ties: lowest slot); the other hit children are pushed in slot order
     const int sel = (tn0 == m) ? 0 : ((tn1 == m) ? 1 : ((tn2 == m) ? 2 : 3));
-    if (h3 && sel != 3) { stack[sp * BLOCK] = stack_enc<ST>(r3); sp++; }
-    if (h2 && sel != 2) { stack[sp * BLOCK] = stack_enc<ST>(r2); sp++; }
-    if (h1 && sel != 1) { stack[sp * BLOCK] = stack_enc<ST>(r1); sp++; }
-    if (h0 && sel != 0) { stack[sp * BLOCK] = stack_enc<ST>(r0); sp++; }
+    if (h3 && sel != 3) { stack.put(sp, r3); sp++; }
+    if (h2 && sel != 2) { stack.put(sp, r2); sp++; }
+    if (h1 && sel != 1) { stack.put(sp, r1); sp++; }
+    if (h0 && sel != 0) { stack.put(sp, r0); sp++; }
     if (h0 || h1 || h2 || h3) cur = (sel == 0) ? r0 : ((sel == 1) ? r1 : ((sel == 2) ? r2 : r3));
-    else if (sp > 0) { sp--; cur = stack_dec(stack[sp * BLOCK]); }
+    else if (sp > 0) { sp--; cur = stack.get(sp); }
     else cur = HJR_TRAV_DONE;
     return 4u;
     }
@@ -709,7 +736,7 @@ struct Hit { float t, b1, b2; uint32_t k, prim; };
 
 // stack: this lane's column of the LDS stack, element i at stack[i * BLOCK]
 template <bool ANY, bool STATS, int WIDTH, int BLOCK, typename ST>
-HD bool traverse(const float4* nodes, const float4* tris, f3 o, f3 d, float tmin, float tmax, Hit& hit, ST* stack, Counters& cnt)
+HD bool traverse(const float4* nodes, const float4* tris, f3 o, f3 d, float tmin, float tmax, Hit& hit, ST& stack, Counters& cnt)
 {
     const BoxRay R = box_ray(o, d);
     int sp = 0;
@@ -739,7 +766,7 @@ HD bool traverse(const float4* nodes, const float4* tris, f3 o, f3 d, float tmin
         }
         if (sp == 0) break;
         sp--;
-        cur = stack_dec(stack[sp * BLOCK]);
+        cur = stack.get(sp);
     }
     return hit.prim != 0xffffffffu;
 }
@@ -765,7 +792,7 @@ HD bool traverse(const float4* nodes, const float4* tris, f3 o, f3 d, float tmin
 struct TravCarry { uint32_t cur; int sp, phase; };
 template <bool STATS, int WIDTH, int BLOCK, typename ST, int CARRY>
 HD bool traverse_fused(const float4* nodes, const float4* tris, const bool a_valid, const f3 ao, const f3 ad, const float a_tmax, const bool b_valid,
-                       const f3 bo, const f3 bd, bool& occluded, Hit& hit, ST* stack, Counters& ca, Counters& cb, const bool resume, TravCarry& tc)
+                       const f3 bo, const f3 bd, bool& occluded, Hit& hit, ST& stack, Counters& ca, Counters& cb, const bool resume, TravCarry& tc)
 {
     const float tmin = 0.001f;
     int phase, sp;
@@ -821,7 +848,7 @@ HD bool traverse_fused(const float4* nodes, const float4* tris, const bool a_val
                 }
             }
             if (!done) {
-                if (sp > 0) { sp--; cur = stack_dec(stack[sp * BLOCK]); }
+                if (sp > 0) { sp--; cur = stack.get(sp); }
                 else done = true;
             }
         }
@@ -905,7 +932,7 @@ HD void hit_program(const KParams& P, const float4* tris, const float4* mats, co
 
 // RayTrace (rt.h:43-69): stand-alone closest-hit query (used by MIS' BSDF-sampled light ray)
 template <bool STATS, bool FULL, int WIDTH, int BLOCK, typename ST>
-HD void ray_trace(const KParams& P, const float4* nodes, const float4* tris, const float4* mats, f3 o, f3 d, HitInfo& prd, ST* stack, unsigned long long* lc)
+HD void ray_trace(const KParams& P, const float4* nodes, const float4* tris, const float4* mats, f3 o, f3 d, HitInfo& prd, ST& stack, unsigned long long* lc)
 {
     Hit h;
     Counters c; c.box = 0; c.tri = 0;
@@ -976,7 +1003,7 @@ HD void start_path(const KParams& P, PathState& ps, uint32_t px, uint32_t py, ui
 }
 
 #ifndef HJR_MIN_WAVES
-#define HJR_MIN_WAVES 3 /* memory-path kernels: keep <= 168 VGPRs = 3 waves per SIMD (2 waves cost 20-30 %, profiles/r01_experiments.md) */
+#define HJR_MIN_WAVES 4 /* memory-path kernels: 128 VGPRs = 4 waves per SIMD (with the short LDS stacks the registers, not LDS, set the occupancy; 3 waves: 329 ms, 4: 279, 5: 283, 6: 315 on the 1 M-triangle scene) */
 #endif
 // Dynamic LDS: [traversal stacks: stack_depth x BLOCK uint32][nodes][tri_geom]  (the last two only when LDSBVH).
 // LDSBVH: the whole BVH + leaf-order triangles are staged into LDS once per persistent workgroup (coalesced dwordx4 loads),
@@ -989,15 +1016,20 @@ extern __shared__ float4 hjr_smem[];
 template <int INTEGRATOR, bool STATS, int BLOCK, bool LDSBVH, bool STACK16, int WIDTH, bool AOVS>
 __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_render_kernel(const KParams P)
 {
-    typedef typename std::conditional<STACK16, uint16_t, uint32_t>::type ST; // stack entry type
-    ST* stack = reinterpret_cast<ST*>(hjr_smem) + threadIdx.x;
+    typedef typename std::conditional<STACK16, uint16_t, uint32_t>::type SE; // stack entry type
+    constexpr int SHORT = LDSBVH ? 0 : HJR_SHORT_STACK;
+    typedef LaneStack<SE, BLOCK, SHORT> ST;
+    ST stack;
+    stack.lds = reinterpret_cast<SE*>(hjr_smem) + threadIdx.x;
+    stack.spill = P.stack_spill + (blockIdx.x * BLOCK + threadIdx.x);
+    stack.spill_stride = P.spill_stride;
     const uint32_t lane = threadIdx.x & 63u;
     const float4* nodes = P.nodes;
     const float4* tris = P.tri_geom;
     const float4* mats = P.materials;
     const float4* lights = P.lights;
     if (LDSBVH) {
-        float4* l_nodes = hjr_smem + (BLOCK * P.stack_depth * (uint32_t)sizeof(ST) + 15u) / 16u;
+        float4* l_nodes = hjr_smem + (BLOCK * P.stack_depth * (uint32_t)sizeof(SE) + 15u) / 16u;
         float4* l_tris = l_nodes + P.n_node_f4;
         for (uint32_t i = threadIdx.x; i < P.n_node_f4; i += BLOCK) l_nodes[i] = P.nodes[i];
         for (uint32_t i = threadIdx.x; i < P.n_tri_f4; i += BLOCK) l_tris[i] = P.tri_geom[i];

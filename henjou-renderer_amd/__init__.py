@@ -18,6 +18,7 @@ LIB_PATH = os.environ.get("HJR_LIB") or os.path.join(PKG_DIR, "libhenjou_hip.so"
 ASSETS = os.path.join(PKG_DIR, "assets")
 
 INTEGRATOR_NEE, INTEGRATOR_PT, INTEGRATOR_MIS = 0, 1, 2
+MODE_DEFAULT, MODE_DENOISE, MODE_DENOISE_UPSCALE2X, MODE_DEBUG = 0, 1, 2, 3  # render_option.h:38-43
 FLAG_STATS, FLAG_ZERO_UNOWNED = 1, 2
 
 
@@ -138,6 +139,9 @@ def lib():
             "hjr_write_png": [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int],
             "hjr_write_pfm": [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32],
             "hjr_render_file": [C.c_char_p, C.c_int],
+            "hjr_denoise": [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32],
+            "hjr_denoise_device": [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p],
+            "hjr_render_denoised": [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_uint32],
         }.items():
             fn = getattr(L, name)
             fn.restype = C.c_int
@@ -358,6 +362,26 @@ class Device:
         _check(lib().hjr_render_device(self._h, C.byref(params), C.c_void_p(d_color),
                                        C.c_void_p(d_albedo) if d_albedo else None, C.c_void_p(d_normal) if d_normal else None,
                                        C.c_void_p(stream) if stream else None), "hjr_render_device")
+
+    def denoise(self, mode, color, albedo=None, normal=None):
+        """OptixDenoiserManager::denoise() replacement on host float4 images (hjr_denoise); returns AOV_Output."""
+        color = np.ascontiguousarray(color, dtype=np.float32)
+        h, w = color.shape[:2]
+        ow, oh = (2 * w, 2 * h) if mode == MODE_DENOISE_UPSCALE2X else (w, h)
+        a = None if albedo is None else np.ascontiguousarray(albedo, dtype=np.float32)
+        n = None if normal is None else np.ascontiguousarray(normal, dtype=np.float32)
+        out = np.zeros((oh, ow, 4), dtype=np.float32)
+        _check(lib().hjr_denoise(self._h, mode, w, h, color.ctypes.data, None if a is None else a.ctypes.data,
+                                 None if n is None else n.ctypes.data, out.ctypes.data, ow, oh), "hjr_denoise")
+        return out
+
+    def render_denoised(self, params, mode, out_w=None, out_h=None):
+        """One frame in a render mode, AOVs kept on the device (hjr_render_denoised); returns AOV_Output."""
+        ow = out_w if out_w is not None else (2 * params.width if mode == MODE_DENOISE_UPSCALE2X else params.width)
+        oh = out_h if out_h is not None else (2 * params.height if mode == MODE_DENOISE_UPSCALE2X else params.height)
+        out = np.zeros((oh, ow, 4), dtype=np.float32)
+        _check(lib().hjr_render_denoised(self._h, C.byref(params), mode, out.ctypes.data, ow, oh), "hjr_render_denoised")
+        return out
 
     def synchronize(self):
         _check(lib().hjr_synchronize(self._h), "hjr_synchronize")

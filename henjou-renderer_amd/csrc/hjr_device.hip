@@ -15,6 +15,7 @@
 #include "../../include/henjou_hip.h"
 #include "../host/frame.hpp"
 #include "hjr_kernel.hip.h"
+#include "hjr_denoise.hip.h"
 
 namespace hjr {
 void set_error(const std::string& s);
@@ -55,6 +56,7 @@ struct hjr_ctx {
     DevBuf d_color, d_albedo, d_normal; // staging for hjr_render (host buffers)
     DevBuf d_part_color, d_part_albedo, d_part_normal; // chunk sums [n_chunks][H][W] float4
     DevBuf d_spill; // overflow of the short traversal stacks (memory-path kernels)
+    DevBuf d_dn_a, d_dn_b, d_dn_out; // denoise ping-pong / host-entry staging
     hjr_stats stats;
     bool event_pending = false;
     int blocks_per_cu = 0; // 0 = ask the occupancy API
@@ -107,7 +109,7 @@ extern "C" void hjr_destroy(hjr_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    for (DevBuf* b : { &c->d_nodes, &c->d_tri_geom, &c->d_tri_shade, &c->d_tri_inst, &c->d_materials, &c->d_lights, &c->d_lut, &c->d_spill,
+    for (DevBuf* b : { &c->d_nodes, &c->d_tri_geom, &c->d_tri_shade, &c->d_tri_inst, &c->d_materials, &c->d_lights, &c->d_lut, &c->d_spill, &c->d_dn_a, &c->d_dn_b, &c->d_dn_out,
                        &c->d_texels, &c->d_tex_desc, &c->d_srgb_lut, &c->d_sky, &c->d_work, &c->d_color, &c->d_albedo, &c->d_normal, &c->d_part_color, &c->d_part_albedo, &c->d_part_normal })
         b->release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -397,6 +399,99 @@ extern "C" int hjr_render_device(hjr_ctx* c, const hjr_params* p, void* d_color,
     if (!c) { set_error("hjr_render_device: null context"); return HJR_ERR_ARG; }
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
     return render_impl(c, p, d_color, d_albedo, d_normal, st);
+}
+
+static bool ensure(DevBuf& b, size_t bytes)
+{
+    if (b.cap >= bytes) return true;
+    b.release();
+    if (hipMalloc(&b.p, bytes) != hipSuccess) return false;
+    b.cap = bytes;
+    return true;
+}
+
+// OptixDenoiserManager::denoise() replacement (csrc/hjr_denoise.hip.h), device buffers, asynchronous on `hip_stream`
+extern "C" int hjr_denoise_device(hjr_ctx* c, int render_mode, uint32_t in_w, uint32_t in_h, const void* d_color, const void* d_albedo,
+                                  const void* d_normal, void* d_out, uint32_t out_w, uint32_t out_h, void* hip_stream)
+{
+    if (!c || !d_color || !d_out) { set_error("hjr_denoise: null argument"); return HJR_ERR_ARG; }
+    if (in_w == 0 || in_h == 0 || in_w > 16384 || in_h > 16384) { set_error("hjr_denoise: bad input size"); return HJR_ERR_ARG; }
+    const bool up = render_mode == HJR_MODE_DENOISE_UPSCALE2X;
+    if (render_mode != HJR_MODE_DEFAULT && render_mode != HJR_MODE_DENOISE && !up) { set_error("hjr_denoise: unknown render mode"); return HJR_ERR_ARG; }
+    if (!up && (out_w != in_w || out_h != in_h)) { set_error("hjr_denoise: output size must equal the input size in this mode"); return HJR_ERR_ARG; }
+    if (up && (out_w / 2u != in_w || out_h / 2u != in_h)) { set_error("hjr_denoise: DenoiseUpScale2X renders at (out_w / 2, out_h / 2)"); return HJR_ERR_ARG; }
+    if (render_mode != HJR_MODE_DEFAULT && (!d_albedo || !d_normal)) { set_error("hjr_denoise: the albedo and normal guide AOVs are required"); return HJR_ERR_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    const size_t in_bytes = (size_t)in_w * in_h * 16;
+    if (render_mode == HJR_MODE_DEFAULT) { // blendFactor 1: the output is the input (denoiser.h:94-97)
+        if (d_out != d_color) HIPCHK(hipMemcpyAsync(d_out, d_color, in_bytes, hipMemcpyDeviceToDevice, st));
+        return HJR_OK;
+    }
+    if (!ensure(c->d_dn_a, in_bytes) || !ensure(c->d_dn_b, in_bytes)) { set_error("hjr_denoise: allocation failed"); return HJR_ERR_DEVICE; }
+    const dim3 block(256), grid((in_w + 63) / 64, (in_h + 3) / 4);
+    const float4* src = (const float4*)d_color;
+    float4* pp[2] = { (float4*)c->d_dn_a.p, (float4*)c->d_dn_b.p };
+    for (int it = 0; it < HJR_ATROUS_PASSES; it++) {
+        float4* dst = (!up && it == HJR_ATROUS_PASSES - 1) ? (float4*)d_out : pp[it & 1];
+        hipLaunchKernelGGL(hjr_atrous_kernel, grid, block, 0, st, src, (const float4*)d_normal, (const float4*)d_albedo, dst, (int)in_w, (int)in_h,
+                           1 << it, it < 2 ? 0.0f : 1.0f / (float)(1 << (it - 2))); // colour term: off, off, 1, 0.5, 0.25
+        src = dst;
+    }
+    if (up) {
+        const dim3 g2((out_w + 63) / 64, (out_h + 3) / 4);
+        hipLaunchKernelGGL(hjr_upscale2x_kernel, g2, block, 0, st, src, (float4*)d_out, (int)in_w, (int)in_h, (int)out_w, (int)out_h);
+    }
+    HIPCHK(hipGetLastError());
+    return HJR_OK;
+}
+
+// host-buffer form (what Renderer's frame loop does with AOV_Color / AOV_Albedo / AOV_Normal -> AOV_Output); synchronous
+extern "C" int hjr_denoise(hjr_ctx* c, int render_mode, uint32_t in_w, uint32_t in_h, const float* color, const float* albedo, const float* normal,
+                           float* out, uint32_t out_w, uint32_t out_h)
+{
+    if (!c || !color || !out) { set_error("hjr_denoise: null argument"); return HJR_ERR_ARG; }
+    if (in_w == 0 || in_h == 0 || out_w == 0 || out_h == 0) { set_error("hjr_denoise: empty image"); return HJR_ERR_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    const size_t in_bytes = (size_t)in_w * in_h * 16, out_bytes = (size_t)out_w * out_h * 16;
+    if (!ensure(c->d_color, in_bytes) || !ensure(c->d_albedo, in_bytes) || !ensure(c->d_normal, in_bytes) || !ensure(c->d_dn_out, out_bytes)) {
+        set_error("hjr_denoise: allocation failed");
+        return HJR_ERR_DEVICE;
+    }
+    HIPCHK(hipMemcpyAsync(c->d_color.p, color, in_bytes, hipMemcpyHostToDevice, c->stream));
+    if (albedo) HIPCHK(hipMemcpyAsync(c->d_albedo.p, albedo, in_bytes, hipMemcpyHostToDevice, c->stream));
+    if (normal) HIPCHK(hipMemcpyAsync(c->d_normal.p, normal, in_bytes, hipMemcpyHostToDevice, c->stream));
+    const int rc = hjr_denoise_device(c, render_mode, in_w, in_h, c->d_color.p, albedo ? c->d_albedo.p : nullptr, normal ? c->d_normal.p : nullptr,
+                                      c->d_dn_out.p, out_w, out_h, c->stream);
+    if (rc != HJR_OK) return rc;
+    HIPCHK(hipMemcpyAsync(out, c->d_dn_out.p, out_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return HJR_OK;
+}
+
+// One frame of Renderer's loop in a Denoise mode, on the device: optixLaunch -> denoise -> cpyGPUBufferToHost(AOV_Output)
+// (renderer.h:1229-1281).  p->width x p->height is the RENDER size (already halved by the caller for DenoiseUpScale2X).
+extern "C" int hjr_render_denoised(hjr_ctx* c, const hjr_params* p, int render_mode, float* out, uint32_t out_w, uint32_t out_h)
+{
+    if (!c || !p || !out) { set_error("hjr_render_denoised: null argument"); return HJR_ERR_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    const size_t in_bytes = (size_t)p->width * p->height * 16, out_bytes = (size_t)out_w * out_h * 16;
+    if (in_bytes == 0 || out_bytes == 0) { set_error("hjr_render_denoised: empty image"); return HJR_ERR_ARG; }
+    const bool guides = render_mode != HJR_MODE_DEFAULT;
+    if (!ensure(c->d_color, in_bytes) || (guides && (!ensure(c->d_albedo, in_bytes) || !ensure(c->d_normal, in_bytes))) || !ensure(c->d_dn_out, out_bytes)) {
+        set_error("hjr_render_denoised: allocation failed");
+        return HJR_ERR_DEVICE;
+    }
+    HIPCHK(hipMemsetAsync(c->d_color.p, 0, in_bytes, c->stream));
+    if (guides) { HIPCHK(hipMemsetAsync(c->d_albedo.p, 0, in_bytes, c->stream)); HIPCHK(hipMemsetAsync(c->d_normal.p, 0, in_bytes, c->stream)); }
+    int rc = render_impl(c, p, c->d_color.p, guides ? c->d_albedo.p : nullptr, guides ? c->d_normal.p : nullptr, c->stream);
+    if (rc != HJR_OK) return rc;
+    rc = hjr_denoise_device(c, render_mode, p->width, p->height, c->d_color.p, guides ? c->d_albedo.p : nullptr, guides ? c->d_normal.p : nullptr,
+                            c->d_dn_out.p, out_w, out_h, c->stream);
+    if (rc != HJR_OK) return rc;
+    HIPCHK(hipMemcpyAsync(out, c->d_dn_out.p, out_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return HJR_OK;
 }
 
 extern "C" int hjr_synchronize(hjr_ctx* c)

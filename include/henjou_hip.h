@@ -184,6 +184,19 @@ int hjr_render(hjr_ctx*, const hjr_params*, float* aov_color, float* aov_albedo,
 int hjr_render_device(hjr_ctx*, const hjr_params*, void* d_aov_color, void* d_aov_albedo, void* d_aov_normal,
                       void* hip_stream);
 int hjr_synchronize(hjr_ctx*);
+/* OptixDenoiserManager::layerSet + denoise() — renderer/denoiser.h:42-189, renderer/renderer.h:1093-1120, 1258-1270:
+ * (aov_color | guide albedo | guide normal) of in_w x in_h -> AOV_Output of out_w x out_h.  The OptiX AI network is closed, so
+ * this is a REPLACEMENT with the same data flow, not a reproduction of its pixels: HJR_MODE_DEFAULT copies
+ * (blendFactor 1), HJR_MODE_DENOISE runs a 5-pass edge-avoiding a-trous filter guided by the two AOVs (out size == in size),
+ * HJR_MODE_DENOISE_UPSCALE2X filters at (out_w / 2, out_h / 2) (renderer.h:1096-1099) and upscales 2x bilinearly. */
+int hjr_denoise(hjr_ctx*, int render_mode, uint32_t in_w, uint32_t in_h, const float* aov_color, const float* aov_albedo,
+                const float* aov_normal, float* out, uint32_t out_w, uint32_t out_h);
+/* One frame of the loop in any render mode, kept on the device: launch at p->width x p->height (the caller halves it for
+ * DenoiseUpScale2X, renderer.h:1096-1099), hjr_denoise_device, download of AOV_Output only (renderer.h:1229-1281).  Synchronous. */
+int hjr_render_denoised(hjr_ctx*, const hjr_params*, int render_mode, float* out, uint32_t out_w, uint32_t out_h);
+/* the same on device pointers (float4 images), asynchronous on `hip_stream` (NULL = the context's stream) */
+int hjr_denoise_device(hjr_ctx*, int render_mode, uint32_t in_w, uint32_t in_h, const void* d_color, const void* d_albedo,
+                       const void* d_normal, void* d_out, uint32_t out_w, uint32_t out_h, void* hip_stream);
 int hjr_get_stats(hjr_ctx*, hjr_stats* out);
 
 /* ---------------- output stage (host) ---------------- */

@@ -1459,3 +1459,79 @@ void hjo_tonemap_to_srgb8(const float* rgba, uint8_t* out, uint32_t n, int mode)
     }
 }
 float hjo_tonemap(float x, int mode) { return mode == 1 ? tonemap_uchimura(x) : (mode == 2 ? tonemap_aces(x) : x); }
+
+/* ------------------------------------------------------------------ denoise-mode replacement (build-defined; checker of
+ * henjou-renderer_amd/csrc/hjr_denoise.hip.h, whose header states the algorithm: 5-pass edge-avoiding a-trous filter guided by
+ * the albedo / normal AOVs, optional 2x bilinear upscale).  Data flow of renderer/denoiser.h:42-189 + renderer.h:1093-1120,
+ * 1258-1270; the OptiX network itself is closed and is not reproduced.  mode: 0 Default (copy), 1 Denoise, 2 DenoiseUpScale2X. */
+static inline float dn_weight(const float* a, const float* b, float rel, float phi)
+{
+    float dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
+    float d2 = dx * dx + dy * dy + dz * dz;
+    float e = -(d2 / rel) / phi;
+    e = fmaxf(e, -87.0f);
+    return fminf(p_exp(e), 1.0f);
+}
+static void dn_atrous_pass(const float* in, const float* normal, const float* albedo, float* out, int W, int H, int step, float c_phi)
+{
+    static const float hk[5] = { 0.0625f, 0.25f, 0.375f, 0.25f, 0.0625f };
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            const size_t c = ((size_t)y * W + x) * 4;
+            const float s0 = (in[c] + in[c + 1]) + in[c + 2];
+            const float rel = 0.01f + s0 * s0;
+            float sx = 0.0f, sy = 0.0f, sz = 0.0f, cum = 0.0f;
+            for (int j = -2; j <= 2; j++) {
+                int yy = y + j * step; yy = yy < 0 ? 0 : (yy > H - 1 ? H - 1 : yy);
+                for (int i = -2; i <= 2; i++) {
+                    int xx = x + i * step; xx = xx < 0 ? 0 : (xx > W - 1 ? W - 1 : xx);
+                    const size_t t = ((size_t)yy * W + xx) * 4;
+                    const float wc = c_phi > 0.0f ? dn_weight(in + c, in + t, rel, c_phi) : 1.0f;
+                    const float wn = dn_weight(normal + c, normal + t, 1.0f, 0.25f);
+                    const float wa = dn_weight(albedo + c, albedo + t, 1.0f, 0.05f);
+                    const float w = ((wc * wn) * wa) * (hk[j + 2] * hk[i + 2]);
+                    sx = sx + in[t] * w; sy = sy + in[t + 1] * w; sz = sz + in[t + 2] * w;
+                    cum = cum + w;
+                }
+            }
+            out[c] = sx / cum; out[c + 1] = sy / cum; out[c + 2] = sz / cum; out[c + 3] = in[c + 3];
+        }
+}
+int hjo_denoise(int mode, uint32_t in_w, uint32_t in_h, const float* color, const float* albedo, const float* normal, float* out,
+                uint32_t out_w, uint32_t out_h)
+{
+    const size_t n = (size_t)in_w * in_h * 4;
+    if (mode == 0) { if (out_w != in_w || out_h != in_h) return -1; memcpy(out, color, n * sizeof(float)); return 0; }
+    if (mode == 1 && (out_w != in_w || out_h != in_h)) return -1;
+    if (mode == 2 && (out_w / 2u != in_w || out_h / 2u != in_h)) return -1;
+    if (mode != 1 && mode != 2) return -1;
+    float* a = (float*)malloc(n * sizeof(float));
+    float* b = (float*)malloc(n * sizeof(float));
+    if (!a || !b) { free(a); free(b); return -2; }
+    const float* src = color;
+    float* pp[2] = { a, b };
+    for (int it = 0; it < 5; it++) {
+        float* dst = pp[it & 1];
+        dn_atrous_pass(src, normal, albedo, dst, (int)in_w, (int)in_h, 1 << it, it < 2 ? 0.0f : 1.0f / (float)(1 << (it - 2)));
+        src = dst;
+    }
+    if (mode == 1) memcpy(out, src, n * sizeof(float));
+    else {
+        const int iw = (int)in_w, ih = (int)in_h;
+        for (int Y = 0; Y < (int)out_h; Y++)
+            for (int X = 0; X < (int)out_w; X++) {
+                const int x0 = (X & 1) ? (X >> 1) : (X >> 1) - 1, y0 = (Y & 1) ? (Y >> 1) : (Y >> 1) - 1;
+                const float fx = (X & 1) ? 0.25f : 0.75f, fy = (Y & 1) ? 0.25f : 0.75f;
+                int xa = x0 < 0 ? 0 : (x0 > iw - 1 ? iw - 1 : x0), xb = x0 + 1 < 0 ? 0 : (x0 + 1 > iw - 1 ? iw - 1 : x0 + 1);
+                int ya = y0 < 0 ? 0 : (y0 > ih - 1 ? ih - 1 : y0), yb = y0 + 1 < 0 ? 0 : (y0 + 1 > ih - 1 ? ih - 1 : y0 + 1);
+                const float gx = 1.0f - fx, gy = 1.0f - fy;
+                for (int k = 0; k < 4; k++) {
+                    const float pa = src[((size_t)ya * iw + xa) * 4 + k], pb = src[((size_t)ya * iw + xb) * 4 + k];
+                    const float pc = src[((size_t)yb * iw + xa) * 4 + k], pd = src[((size_t)yb * iw + xb) * 4 + k];
+                    out[((size_t)Y * out_w + X) * 4 + k] = (pa * gx + pb * fx) * gy + (pc * gx + pd * fx) * fy;
+                }
+            }
+    }
+    free(a); free(b);
+    return 0;
+}

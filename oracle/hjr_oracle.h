@@ -138,6 +138,9 @@ void hjo_lut_fetch(const uint8_t* rgba, int w, int h, float u, float v, float* o
 void hjo_float4_to_srgb8(const float* rgba, uint8_t* out, uint32_t n_pixels);
 /* kernel/color.h tonemappers (1 = Uchimura :10-53, 2 = ACES :55-63) followed by the stage above */
 void hjo_tonemap_to_srgb8(const float* rgba, uint8_t* out, uint32_t n_pixels, int mode);
+/* denoise-mode replacement (see hjr_oracle.c): mode 0 Default (copy), 1 Denoise, 2 DenoiseUpScale2X; float4 images; 0 = ok */
+int hjo_denoise(int mode, uint32_t in_w, uint32_t in_h, const float* color, const float* albedo, const float* normal, float* out,
+                uint32_t out_w, uint32_t out_h);
 float hjo_tonemap(float x, int mode);
 
 #ifdef __cplusplus

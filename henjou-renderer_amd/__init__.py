@@ -139,6 +139,7 @@ def lib():
             "hjr_write_png": [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int],
             "hjr_write_pfm": [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32],
             "hjr_render_file": [C.c_char_p, C.c_int],
+            "hjr_load_image_rgba8": [C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p],
             "hjr_denoise": [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32],
             "hjr_denoise_device": [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p],
             "hjr_render_denoised": [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_uint32],
@@ -179,6 +180,16 @@ def load_png(path):
     p = C.c_void_p()
     w, h = C.c_int(), C.c_int()
     _check(lib().hjr_load_png_rgba8(os.fsencode(path), C.byref(p), C.byref(w), C.byref(h)), "hjr_load_png_rgba8")
+    a = _np(p.value, w.value * h.value * 4, np.uint8).reshape(h.value, w.value, 4)
+    lib().hjr_free(p)
+    return a
+
+
+def load_image(path):
+    """Material texture decode: PNG or baseline JPEG by signature (hjr_load_image_rgba8) -> uint8 [h, w, 4]."""
+    p = C.c_void_p()
+    w, h = C.c_int(), C.c_int()
+    _check(lib().hjr_load_image_rgba8(os.fsencode(path), C.byref(p), C.byref(w), C.byref(h)), "hjr_load_image_rgba8")
     a = _np(p.value, w.value * h.value * 4, np.uint8).reshape(h.value, w.value, 4)
     lib().hjr_free(p)
     return a

@@ -18,6 +18,7 @@ static thread_local std::string g_err;
 void set_error(const std::string& s) { g_err = s; }
 bool write_png(const std::string& path, const uint8_t* rgba, uint32_t w, uint32_t h, bool flip_y, std::string& err);
 bool read_png_rgba8(const std::string& path, std::vector<uint8_t>& rgba, int& w, int& h, std::string& err);
+bool read_image_rgba8(const std::string& path, std::vector<uint8_t>& rgba, int& w, int& h, std::string& err);
 bool write_pfm(const std::string& path, const float* rgba, uint32_t w, uint32_t h, std::string& err);
 bool read_hdr_rgba32f(const std::string& path, std::vector<float>& rgba, int& w, int& h, std::string& err);
 void float4_to_srgb8(const float* rgba, uint8_t* out, uint32_t n);
@@ -107,6 +108,21 @@ extern "C" int hjr_load_png_rgba8(const char* path, uint8_t** rgba, int* w, int*
     std::vector<uint8_t> px;
     std::string err;
     if (!hjr::read_png_rgba8(path, px, *w, *h, err)) {
+        set_error(err);
+        return err.rfind("cannot open", 0) == 0 ? HJR_ERR_IO : HJR_ERR_PARSE;
+    }
+    *rgba = (uint8_t*)malloc(px.size());
+    if (!*rgba) { set_error("out of memory"); return HJR_ERR_ARG; }
+    memcpy(*rgba, px.data(), px.size());
+    return HJR_OK;
+}
+
+extern "C" int hjr_load_image_rgba8(const char* path, uint8_t** rgba, int* w, int* h)
+{
+    if (!path || !rgba || !w || !h) { set_error("hjr_load_image_rgba8: null argument"); return HJR_ERR_ARG; }
+    std::vector<uint8_t> px;
+    std::string err;
+    if (!hjr::read_image_rgba8(path, px, *w, *h, err)) {
         set_error(err);
         return err.rfind("cannot open", 0) == 0 ? HJR_ERR_IO : HJR_ERR_PARSE;
     }

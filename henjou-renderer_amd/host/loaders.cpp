@@ -15,6 +15,7 @@
 namespace hjr {
 
 bool read_png_rgba8(const std::string& path, std::vector<uint8_t>& rgba, int& w, int& h, std::string& err);
+bool read_image_rgba8(const std::string& path, std::vector<uint8_t>& rgba, int& w, int& h, std::string& err);
 
 static bool read_file(const std::string& path, std::string& out)
 {
@@ -291,7 +292,8 @@ double arr_or(const Json* a, size_t i, double d)
 
 // loadTexture(textures, known_tex, name, modelpath, type) — texture_load.h:7-20: de-duplicate by file name, return slot.
 // Texture(filename, type) (renderer/texture.h:22-38) decodes with stbi_load(..., STBI_rgb_alpha); here: the PNG decoder of
-// image_io.cpp (JPEG is not supported and is reported as an error instead of the reference's silent "NOT FOUND").
+// image_io.cpp or the baseline JPEG decoder of jpeg.cpp, by file signature (other formats and progressive JPEG are reported
+// as an error instead of the reference's silent "NOT FOUND").
 int texture_slot(SceneData& sc, std::map<std::string, int>& known, const Model& m, const Json* texinfo, const std::string& dir, bool srgb)
 {
     if (!texinfo) return -1;
@@ -308,7 +310,7 @@ int texture_slot(SceneData& sc, std::map<std::string, int>& known, const Model& 
     SceneData::TexturePixels px;
     int w = 0, h = 0;
     std::string err;
-    if (!read_png_rgba8(dir + "/" + uri, px.rgba, w, h, err)) throw JsonError("texture " + uri + ": " + err);
+    if (!read_image_rgba8(dir + "/" + uri, px.rgba, w, h, err)) throw JsonError("texture " + uri + ": " + err);
     px.width = (uint32_t)w; px.height = (uint32_t)h; px.srgb = srgb ? 1 : 0;
     sc.texture_files.push_back(uri);
     sc.textures.push_back(std::move(px));

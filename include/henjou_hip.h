@@ -160,6 +160,8 @@ int hjr_scene_eval_transforms(const hjr_scene*, float time, float* transforms12,
 int hjr_scene_eval_camera(const hjr_scene*, const hjr_render_option*, float time, hjr_camera* out);
 /* Texture(LUT_path, NonColor) — renderer/texture.h:16-39, loader/texture_load.h:7-20: 8-bit RGBA, caller frees with hjr_free */
 int hjr_load_png_rgba8(const char* path, uint8_t** rgba, int* w, int* h);
+/* the material-texture form of the same loader: PNG or baseline JPEG by file signature (stbi_load decodes both) */
+int hjr_load_image_rgba8(const char* path, uint8_t** rgba, int* w, int* h);
 /* HDRTexture(filename, background) — renderer/texture.h:67-100 (stbi_loadf): Radiance .hdr (RGBE) -> float RGBA (a = 0), caller frees with hjr_free */
 int hjr_load_hdr_rgba32f(const char* path, float** rgba, int* w, int* h);
 void hjr_free(void*);

@@ -15,6 +15,7 @@ bool write_png(const std::string& path, const uint8_t* rgba, uint32_t w, uint32_
 bool read_png_rgba8(const std::string& path, std::vector<uint8_t>& rgba, int& w, int& h, std::string& err);
 void float4_to_srgb8(const float* rgba, uint8_t* out, uint32_t n);
 void tonemap_to_srgb8(const float* rgba, uint8_t* out, uint32_t n, int mode);
+bool read_jpeg_rgba8(const std::vector<uint8_t>& file, std::vector<uint8_t>& rgba, int& w, int& h, std::string& err);
 }
 
 #define CHECK(c) do { if (!(c)) { fprintf(stderr, "CHECK failed: %s (line %d)\n", #c, __LINE__); return 1; } } while (0)
@@ -86,6 +87,25 @@ int main(int argc, char** argv)
         int w = 0, h = 0;
         CHECK(hjr::read_png_rgba8(tmp + "/san.png", back, w, h, err) && w == 24 && h == 16);
         hjo_destroy(c);
+    }
+    // JPEG decoder on a valid stream and on corrupted copies of it (tmp/fuzz.jpg is written by the test)
+    if (FILE* f = fopen((tmp + "/fuzz.jpg").c_str(), "rb")) {
+        std::vector<uint8_t> raw;
+        int ch;
+        while ((ch = fgetc(f)) != EOF) raw.push_back((uint8_t)ch);
+        fclose(f);
+        std::vector<uint8_t> px;
+        int w = 0, h = 0;
+        CHECK(hjr::read_jpeg_rgba8(raw, px, w, h, err) && w > 0 && h > 0 && px.size() == (size_t)w * h * 4);
+        uint32_t lcg = 12345u;
+        auto rnd = [&](uint32_t n) { lcg = lcg * 1664525u + 1013904223u; return (lcg >> 8) % n; };
+        for (int trial = 0; trial < 400; trial++) {
+            std::vector<uint8_t> b = raw;
+            if (trial % 4 == 0) b.resize(2 + rnd((uint32_t)b.size() - 2));
+            else for (uint32_t k = 0, n = 1 + rnd(6); k < n; k++) b[2 + rnd((uint32_t)b.size() - 2)] = (uint8_t)rnd(256);
+            std::string e2;
+            (void)hjr::read_jpeg_rgba8(b, px, w, h, e2);
+        }
     }
     printf("sanitize_driver ok\n");
     return 0;

@@ -12,7 +12,7 @@ def test_frame_build_is_thread_count_invariant(tmp_path):
     exe = str(tmp_path / "frame_build_bench")
     host = os.path.join(ROOT, "henjou-renderer_amd", "host")
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + ROOT, os.path.join(ROOT, "tools", "frame_build_bench.cpp"),
-                           os.path.join(host, "loaders.cpp"), os.path.join(host, "frame.cpp"), os.path.join(host, "image_io.cpp"),
+                           os.path.join(host, "loaders.cpp"), os.path.join(host, "frame.cpp"), os.path.join(host, "image_io.cpp"), os.path.join(host, "jpeg.cpp"),
                            "-lz", "-pthread", "-o", exe])
     sdir = str(tmp_path / "scene")
     subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_stress_scene.py"), sdir, "--spheres", "12", "--segments", "96"],

@@ -1,5 +1,5 @@
 // Host-side timing of hjr::build_frame (flatten + BVH build + emit) for a render_option.json scene.
-//   g++ -O3 -std=c++17 -I. tools/frame_build_bench.cpp henjou-renderer_amd/host/{loaders,frame,image_io}.cpp -lz -pthread -o /tmp/fbb
+//   g++ -O3 -std=c++17 -I. tools/frame_build_bench.cpp henjou-renderer_amd/host/{loaders,frame,image_io,jpeg}.cpp -lz -pthread -o /tmp/fbb
 //   /tmp/fbb <dir containing render_option + Model/> <render_option.json> [repeats]
 #include <chrono>
 #include <cstdio>

@@ -56,6 +56,7 @@ struct hjr_ctx {
     DevBuf d_color, d_albedo, d_normal; // staging for hjr_render (host buffers)
     DevBuf d_part_color, d_part_albedo, d_part_normal; // chunk sums [n_chunks][H][W] float4
     DevBuf d_spill; // overflow of the short traversal stacks (memory-path kernels)
+    DevBuf d_tiles; // [tile_order | tile_class] of the cost-ordered tile list
     DevBuf d_dn_a, d_dn_b, d_dn_out; // denoise ping-pong / host-entry staging
     hjr_stats stats;
     bool event_pending = false;
@@ -109,7 +110,7 @@ extern "C" void hjr_destroy(hjr_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    for (DevBuf* b : { &c->d_nodes, &c->d_tri_geom, &c->d_tri_shade, &c->d_tri_inst, &c->d_materials, &c->d_lights, &c->d_lut, &c->d_spill, &c->d_dn_a, &c->d_dn_b, &c->d_dn_out,
+    for (DevBuf* b : { &c->d_nodes, &c->d_tri_geom, &c->d_tri_shade, &c->d_tri_inst, &c->d_materials, &c->d_lights, &c->d_lut, &c->d_spill, &c->d_tiles, &c->d_dn_a, &c->d_dn_b, &c->d_dn_out,
                        &c->d_texels, &c->d_tex_desc, &c->d_srgb_lut, &c->d_sky, &c->d_work, &c->d_color, &c->d_albedo, &c->d_normal, &c->d_part_color, &c->d_part_albedo, &c->d_part_normal })
         b->release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -280,7 +281,7 @@ static int render_impl(hjr_ctx* c, const hjr_params* p, void* d_color, void* d_a
     if (n_items >= 0xffffffffull) { set_error("hjr_render: image too large"); return HJR_ERR_ARG; }
 
     // work area: [0] queue head, [16..] HJR_NSTAT uint64 counters
-    const size_t work_bytes = 16 + (HJR_NSTAT + 20) * 8; // +20: phase clocks / lane-occupancy sums of the HJR_TIMING diagnostic build
+    const size_t work_bytes = 16 + (HJR_NSTAT + 20) * 8 + 32; // +20: phase clocks / lane-occupancy sums of the HJR_TIMING diagnostic build; +32: tile-class counters
     if (c->d_work.cap < work_bytes) {
         std::vector<unsigned char> z(work_bytes, 0);
         if (!c->d_work.upload(z.data(), work_bytes, st)) { set_error("hjr_render: work buffer allocation failed"); return HJR_ERR_DEVICE; }
@@ -347,6 +348,27 @@ static int render_impl(hjr_ctx* c, const hjr_params* p, void* d_color, void* d_a
     int lds_mode = c->frame.lds_mode;
     if (lds_mode == 0 && c->frame.width == 2) lds_mode = 3;
     HIPCHK(hipEventRecord(c->ev0, st));
+    // cost-ordered tile list (hjr_classify_tiles_kernel): HJR_TILE_ORDER=0 keeps the plain round-robin order
+    static const bool tile_order_on = !(getenv("HJR_TILE_ORDER") && atoi(getenv("HJR_TILE_ORDER")) == 0);
+    if (tile_order_on && owned > 0) {
+        const size_t tb = (size_t)owned * 4;
+        if (c->d_tiles.cap < 2 * tb) {
+            c->d_tiles.release();
+            if (hipMalloc(&c->d_tiles.p, 2 * tb) != hipSuccess) { set_error("hjr_render: tile list allocation failed"); return HJR_ERR_DEVICE; }
+            c->d_tiles.cap = 2 * tb;
+        }
+        kp.n_owned_tiles = (uint32_t)owned;
+        kp.tile_order_w = (uint32_t*)c->d_tiles.p;
+        kp.tile_class = (uint32_t*)((char*)c->d_tiles.p + tb);
+        kp.tile_count = (uint32_t*)((char*)c->d_work.p + 16 + (HJR_NSTAT + 20) * 8);
+        const unsigned cg = (unsigned)std::min<uint64_t>(owned, (uint64_t)c->n_cus * 16);
+        const size_t csm = (size_t)64 * kp.stack_depth * 4;
+        if (c->frame.width == 2) hipLaunchKernelGGL(hjr_classify_tiles_kernel<2>, dim3(cg), dim3(64), csm, st, kp);
+        else hipLaunchKernelGGL(hjr_classify_tiles_kernel<4>, dim3(cg), dim3(64), csm, st, kp);
+        hipLaunchKernelGGL(hjr_order_tiles_kernel, dim3((unsigned)((owned + 255) / 256)), dim3(256), 0, st, kp);
+        HIPCHK(hipGetLastError());
+        kp.tile_order = (const uint32_t*)c->d_tiles.p;
+    }
     int lrc = 0;
     switch (p->integrator * 2 + (stats ? 1 : 0)) {
     case 0: lrc = launch<HJR_INTEGRATOR_NEE, false>(c, kp, n_items, lds_mode, st); break;

@@ -47,6 +47,11 @@ struct KParams {
     uint32_t n_mat_f4, n_light_f4;   // float4 counts of materials[] / lights[] (staged behind the triangles in the LDS variant)
     uint32_t stack_depth;            // traversal stack entries per lane (BVH depth + 1)
     uint32_t* stack_spill;           // memory-path kernels: overflow of the short LDS stacks, [level][lane]
+    const uint32_t* tile_order;      // owned tiles, expensive first (hjr_classify_tiles_kernel); null = plain round-robin order
+    uint32_t* tile_order_w;          // the same buffer, writable (pre-pass kernels)
+    uint32_t* tile_class;            // per owned tile: 0 background, 1 diffuse, 2 specular / metallic first hit
+    uint32_t* tile_count;            // [0..2] tiles per class, [3..5] scatter cursors
+    uint32_t n_owned_tiles;
     uint32_t spill_stride;           // lanes in the grid
     float4* part_color;              // [n_chunks][height][width] chunk sums when n_chunks > 1
     float4* part_albedo;
@@ -1093,46 +1098,6 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
 #endif
 
     for (;;) {
-        // ---- ray-queue refill (ballot + mbcnt prefix): idle lanes take consecutive items from the wave's private range
-        //      [w_next, w_end); when it runs dry the wave fetches the next 64 items with ONE atomic on the global head.
-        {
-            const bool need = !has_item && !dead && !write_pending && !fin_pending && !sh_valid;
-            const unsigned long long m = __ballot(need);
-            if (m) {
-                const uint32_t n = (uint32_t)__popcll(m);
-                const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                uint32_t q = w_next + prefix;          // wave-uniform w_next / w_end
-                const uint32_t have = w_end - w_next;  // items left in the private range
-                if (n > have) {                        // not enough: lanes beyond `have` come from a fresh range
-                    uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(P.queue_head, 64u);
-                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                    if (prefix >= have) q = base + (prefix - have);
-                    w_next = base + (n - have);
-                    w_end = base + 64u;
-                } else w_next += n;
-                if (need) {
-                    if (q < P.n_owned_items) {
-                        // item q = ((owned tile * n_chunks) + chunk) * 64 + pixel-in-tile: the 64 lanes of a wave start on one
-                        // tile and one sample chunk (coherent primary rays)
-                        const uint32_t tc = q >> 6;
-                        const uint32_t tile = (tc / P.n_chunks) * P.world + P.rank;
-                        const uint32_t chunk = tc % P.n_chunks;
-                        const uint32_t tx = tile % P.tiles_x, ty = tile / P.tiles_x;
-                        const uint32_t px = tx * HJR_TILE + (q & 7u);
-                        const uint32_t py = ty * HJR_TILE + ((q >> 3) & 7u);
-                        if (px < P.width && py < P.height) {
-                            has_item = true; path_live = false;
-                            item = px | (py << 13) | (chunk << 26);
-                            s = chunk * P.chunk_spp;
-                            sumL = V1(0.0f); sumA = V1(0.0f); sumN = V1(0.0f);
-                        }
-                    } else dead = true;
-                }
-            }
-            if (__ballot(!dead) == 0ull) break; // a lane only dies with nothing pending
-        }
-
 #ifdef HJR_TIMING
         { // wave-uniform occupancy sums of the previous round (all lanes are here; flags are lane-private)
             const int n_sh = __popcll(__ballot(dg_shade));
@@ -1178,9 +1143,59 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
                 CMJState rr = path_rng(P, HJR_PX, HJR_PY, s, ps.rng_depth);
                 const float xi_rr = cmj_1d(rr);
                 ps.rng_depth = rr.depth;
-                if (russian_p < xi_rr) { fin_pending = true; close_sample(); }
-                else ps.thr = ps.thr / russian_p;
+                if (russian_p < xi_rr) {
+                    if (sh_valid) { fin_pending = true; close_sample(); } // radiance final once the pending shadow ray is resolved
+                    else { // nothing pending: the sample is final now, and if it was the item's last one the lane refills below
+                        finish_sample(ps.L);
+                        ps.L = V1(0.0f);
+                        close_sample();
+                        if (write_pending) write_out();
+                    }
+                } else ps.thr = ps.thr / russian_p;
             }
+        }
+
+        // ---- ray-queue refill (ballot + mbcnt prefix): idle lanes take consecutive items from the wave's private range
+        //      [w_next, w_end); when it runs dry the wave fetches the next 64 items with ONE atomic on the global head.
+        {
+            const bool need = !has_item && !dead && !write_pending && !fin_pending && !sh_valid;
+            const unsigned long long m = __ballot(need);
+            if (m) {
+                const uint32_t n = (uint32_t)__popcll(m);
+                const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                uint32_t q = w_next + prefix;          // wave-uniform w_next / w_end
+                const uint32_t have = w_end - w_next;  // items left in the private range
+                if (n > have) {                        // not enough: lanes beyond `have` come from a fresh range
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(P.queue_head, 64u);
+                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                    if (prefix >= have) q = base + (prefix - have);
+                    w_next = base + (n - have);
+                    w_end = base + 64u;
+                } else w_next += n;
+                if (need) {
+                    if (q < P.n_owned_items) {
+                        // item q = ((owned tile * n_chunks) + chunk) * 64 + pixel-in-tile: the 64 lanes of a wave start on one
+                        // tile and one sample chunk (coherent primary rays)
+                        const uint32_t tc = q >> 6;
+                        const uint32_t tile = P.tile_order ? P.tile_order[tc / P.n_chunks] : (tc / P.n_chunks) * P.world + P.rank;
+                        const uint32_t chunk = tc % P.n_chunks;
+                        const uint32_t tx = tile % P.tiles_x, ty = tile / P.tiles_x;
+                        const uint32_t px = tx * HJR_TILE + (q & 7u);
+                        const uint32_t py = ty * HJR_TILE + ((q >> 3) & 7u);
+                        if (px < P.width && py < P.height) {
+                            has_item = true; path_live = false;
+                            item = px | (py << 13) | (chunk << 26);
+                            s = chunk * P.chunk_spp;
+                            sumL = V1(0.0f); sumA = V1(0.0f); sumN = V1(0.0f);
+                        }
+                    } else dead = true;
+                }
+            }
+            if (__ballot(!dead) == 0ull) break; // a lane only dies with nothing pending
+        }
+
+        if (!inflight) {
             if (has_item && !path_live) {
                 start_path(P, ps, HJR_PX, HJR_PY, s);
                 if (!fin_pending) ps.L = V1(0.0f); // while fin_pending, ps.L still belongs to the finished path
@@ -1345,9 +1360,14 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
                 fresh = false;
                 ps.rng_depth = st.depth;
                 ps.depth++;
-                if (ps.depth == 10) { // MaxDepth (rt.h:166): the path is over, its last shadow ray is still pending
-                    fin_pending = true;
-                    close_sample();
+                if (ps.depth == 10) { // MaxDepth (rt.h:166): the path is over; its last shadow ray, if any, is still pending
+                    if (sh_valid) { fin_pending = true; close_sample(); }
+                    else {
+                        finish_sample(ps.L);
+                        ps.L = V1(0.0f);
+                        close_sample();
+                        if (write_pending) write_out();
+                    }
                 }
                 HJR_TICK(4)
             }
@@ -1367,6 +1387,53 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
             if (lane == 0 && v) atomicAdd(&P.stats[i], v);
         }
     }
+}
+
+// ---- cost-ordered tile list.  The frame ends when the slowest work item ends, and an item (16 samples of one pixel, each up
+// to 10 bounces, strictly sequential) can run for milliseconds: with plain scanline order the tail of the launch is whatever
+// the last tiles happen to cost (5 ms on a 64 x 64 frame, 15 % of an 18 ms launch when the frame is split over 8 GPUs).
+// One wave per owned tile casts the 64 pixel-centre rays (no RNG), classifies the tile by its costliest first hit
+// (2 = glass / metallic, 1 = other surface, 0 = background or light) and the tiles are handed out class 2 first, background
+// last: longest-processing-time-first scheduling, and waves whose lanes behave alike.  Only the ORDER of the work changes;
+// every pixel is computed exactly as before.
+template <int WIDTH>
+__global__ void __launch_bounds__(64) hjr_classify_tiles_kernel(const KParams P)
+{
+    typedef LaneStack<uint32_t, 64, 0> ST;
+    ST stack;
+    stack.lds = reinterpret_cast<uint32_t*>(hjr_smem) + threadIdx.x;
+    stack.spill = nullptr; stack.spill_stride = 0;
+    for (uint32_t idx = blockIdx.x; idx < P.n_owned_tiles; idx += gridDim.x) {
+        const uint32_t tile = idx * P.world + P.rank;
+        const uint32_t tx = tile % P.tiles_x, ty = tile / P.tiles_x;
+        const uint32_t px = tx * HJR_TILE + (threadIdx.x & 7u), py = ty * HJR_TILE + (threadIdx.x >> 3);
+        uint32_t cls = 0;
+        if (px < P.width && py < P.height) {
+            const float W = (float)P.width, H = (float)P.height;
+            const float u = (2.0f * ((float)px + 0.5f) - W) / H, v = (2.0f * ((float)py + 0.5f) - H) / H;
+            const f3 cd = V(P.cam_dir[0], P.cam_dir[1], P.cam_dir[2]), cu = V(P.cam_up[0], P.cam_up[1], P.cam_up[2]);
+            const f3 cr = V(P.cam_right[0], P.cam_right[1], P.cam_right[2]);
+            const f3 d = normalize(cd * P.cam_f + cr * u + cu * v);
+            Hit h;
+            Counters cnt; cnt.box = cnt.tri = 0;
+            if (traverse<false, false, WIDTH, 64, ST>(P.nodes, P.tri_geom, V(P.cam_pos[0], P.cam_pos[1], P.cam_pos[2]), d, 0.001f, 1e16f, h, stack, cnt)) {
+                const float4* m = P.materials + f2bits(P.tri_geom[h.k * HJR_TRI_F4 + 2].z) * HJR_MAT_F4;
+                const float4 m0 = m[0], m3 = m[3];
+                cls = f2bits(m3.x) != 0 ? 0u : ((f2bits(m3.y) != 0 || m0.w > 0.5f) ? 2u : 1u);
+            }
+        }
+        const uint32_t tcls = __ballot(cls == 2u) ? 2u : (__ballot(cls == 1u) ? 1u : 0u);
+        if (threadIdx.x == 0) { P.tile_class[idx] = tcls; atomicAdd(&P.tile_count[tcls], 1u); }
+    }
+}
+__global__ void __launch_bounds__(256) hjr_order_tiles_kernel(const KParams P)
+{
+    const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
+    if (idx >= P.n_owned_tiles) return;
+    const uint32_t cls = P.tile_class[idx];
+    const uint32_t base = cls == 2u ? 0u : (cls == 1u ? P.tile_count[2] : P.tile_count[2] + P.tile_count[1]);
+    const uint32_t pos = base + atomicAdd(&P.tile_count[3 + cls], 1u);
+    P.tile_order_w[pos] = idx * P.world + P.rank;
 }
 
 // Adds the chunk sums of every owned pixel in chunk order and scales by 1/spp: a fixed summation

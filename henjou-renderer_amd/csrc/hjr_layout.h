@@ -59,7 +59,9 @@
 #define HJR_NSTAT 10 /* order of hjr_stats' uint64 counters */
 
 /* Work-item chunking: a pixel's spp samples are cut into n_chunks runs of chunk_spp consecutive samples
- * (a multiple of the 16-sample CMJ pattern, at most 16 runs); pixel mean = ((c0 + c1) + ... ) * (1/spp), ck = in-order sum
- * of run k.  Depends on spp only, so results do not depend on scheduling, tile sharding or GPU count. */
-static inline uint32_t hjr_chunk_spp(uint32_t spp) { uint32_t n16 = (spp + 15u) / 16u; return 16u * ((n16 + 15u) / 16u); }
+ * (a multiple of 8, at most 64 runs); pixel mean = ((c0 + c1) + ... ) * (1/spp), ck = in-order sum of run k.  Depends on spp
+ * only, so results do not depend on scheduling, tile sharding or GPU count.  A run is one work item, executed by one lane
+ * from its first to its last bounce: its length is the critical path of a launch (16-sample runs: ~4 ms for a pixel inside
+ * the glass sphere, 20 % of an 8-GPU share of the C2 frame), hence runs of 8 (profiles/r01_experiments.md). */
+static inline uint32_t hjr_chunk_spp(uint32_t spp) { uint32_t n8 = (spp + 7u) / 8u; return 8u * ((n8 + 63u) / 64u); }
 static inline uint32_t hjr_n_chunks(uint32_t spp) { uint32_t s = hjr_chunk_spp(spp); return (spp + s - 1u) / s; }

@@ -1343,10 +1343,10 @@ static void render_pixel(job* J, uint32_t x, uint32_t y)
 {
     const hjo_params* P = J->T.P;
     /* build-defined accumulation order: samples are summed in order inside runs of chunk_spp
-     * consecutive samples (a multiple of the 16-sample CMJ pattern, at most 16 runs per pixel), and the run sums
-     * are added in run order.  With one run this is the plain in-order sum. */
-    uint32_t n16 = (P->spp + 15u) / 16u;
-    uint32_t chunk = 16u * ((n16 + 15u) / 16u);
+     * consecutive samples (a multiple of 8, at most 64 runs per pixel), and the run sums are added in run order.
+     * With one run this is the plain in-order sum. */
+    uint32_t n8 = (P->spp + 7u) / 8u;
+    uint32_t chunk = 8u * ((n8 + 63u) / 64u);
     f3 sL = V1(0.0f), sA = V1(0.0f), sN = V1(0.0f);
     for (uint32_t s0 = 0; s0 < P->spp; s0 += chunk) {
         uint32_t s1 = s0 + chunk < P->spp ? s0 + chunk : P->spp;

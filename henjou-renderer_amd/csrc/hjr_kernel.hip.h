@@ -49,8 +49,8 @@ struct KParams {
     uint32_t* stack_spill;           // memory-path kernels: overflow of the short LDS stacks, [level][lane]
     const uint32_t* tile_order;      // owned tiles, expensive first (hjr_classify_tiles_kernel); null = plain round-robin order
     uint32_t* tile_order_w;          // the same buffer, writable (pre-pass kernels)
-    uint32_t* tile_class;            // per owned tile: 0 background, 1 diffuse, 2 specular / metallic first hit
-    uint32_t* tile_count;            // [0..2] tiles per class, [3..5] scatter cursors
+    uint32_t* tile_class;            // per owned tile: costliest first hit of its pixel centres: 0 background / light, 1 Disney, 2 metallic (msGGX), 3 glass
+    uint32_t* tile_count;            // [0..3] tiles per class, [4..7] scatter cursors
     uint32_t n_owned_tiles;
     uint32_t spill_stride;           // lanes in the grid
     float4* part_color;              // [n_chunks][height][width] chunk sums when n_chunks > 1
@@ -1393,7 +1393,7 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
 // to 10 bounces, strictly sequential) can run for milliseconds: with plain scanline order the tail of the launch is whatever
 // the last tiles happen to cost (5 ms on a 64 x 64 frame, 15 % of an 18 ms launch when the frame is split over 8 GPUs).
 // One wave per owned tile casts the 64 pixel-centre rays (no RNG), classifies the tile by its costliest first hit
-// (2 = glass / metallic, 1 = other surface, 0 = background or light) and the tiles are handed out class 2 first, background
+// (3 = glass, 2 = metallic, 1 = other surface, 0 = background or light) and the tiles are handed out class 3 first, background
 // last: longest-processing-time-first scheduling, and waves whose lanes behave alike.  Only the ORDER of the work changes;
 // every pixel is computed exactly as before.
 template <int WIDTH>
@@ -1419,10 +1419,10 @@ __global__ void __launch_bounds__(64) hjr_classify_tiles_kernel(const KParams P)
             if (traverse<false, false, WIDTH, 64, ST>(P.nodes, P.tri_geom, V(P.cam_pos[0], P.cam_pos[1], P.cam_pos[2]), d, 0.001f, 1e16f, h, stack, cnt)) {
                 const float4* m = P.materials + f2bits(P.tri_geom[h.k * HJR_TRI_F4 + 2].z) * HJR_MAT_F4;
                 const float4 m0 = m[0], m3 = m[3];
-                cls = f2bits(m3.x) != 0 ? 0u : ((f2bits(m3.y) != 0 || m0.w > 0.5f) ? 2u : 1u);
+                cls = f2bits(m3.x) != 0 ? 0u : (f2bits(m3.y) != 0 ? 3u : (m0.w > 0.5f ? 2u : 1u));
             }
         }
-        const uint32_t tcls = __ballot(cls == 2u) ? 2u : (__ballot(cls == 1u) ? 1u : 0u);
+        const uint32_t tcls = __ballot(cls == 3u) ? 3u : (__ballot(cls == 2u) ? 2u : (__ballot(cls == 1u) ? 1u : 0u));
         if (threadIdx.x == 0) { P.tile_class[idx] = tcls; atomicAdd(&P.tile_count[tcls], 1u); }
     }
 }
@@ -1431,8 +1431,9 @@ __global__ void __launch_bounds__(256) hjr_order_tiles_kernel(const KParams P)
     const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
     if (idx >= P.n_owned_tiles) return;
     const uint32_t cls = P.tile_class[idx];
-    const uint32_t base = cls == 2u ? 0u : (cls == 1u ? P.tile_count[2] : P.tile_count[2] + P.tile_count[1]);
-    const uint32_t pos = base + atomicAdd(&P.tile_count[3 + cls], 1u);
+    uint32_t base = 0;
+    for (uint32_t c = 3u; c > cls; c--) base += P.tile_count[c];
+    const uint32_t pos = base + atomicAdd(&P.tile_count[4 + cls], 1u);
     P.tile_order_w[pos] = idx * P.world + P.rank;
 }
 

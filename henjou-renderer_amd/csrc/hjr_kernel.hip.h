@@ -1403,6 +1403,7 @@ __global__ void __launch_bounds__(64) hjr_classify_tiles_kernel(const KParams P)
     ST stack;
     stack.lds = reinterpret_cast<uint32_t*>(hjr_smem) + threadIdx.x;
     stack.spill = nullptr; stack.spill_stride = 0;
+    uint32_t n_cls[4] = { 0u, 0u, 0u, 0u }; // per block; one atomic per class at the end (32 k atomics on four words cost 0.4 ms)
     for (uint32_t idx = blockIdx.x; idx < P.n_owned_tiles; idx += gridDim.x) {
         const uint32_t tile = idx * P.world + P.rank;
         const uint32_t tx = tile % P.tiles_x, ty = tile / P.tiles_x;
@@ -1423,18 +1424,31 @@ __global__ void __launch_bounds__(64) hjr_classify_tiles_kernel(const KParams P)
             }
         }
         const uint32_t tcls = __ballot(cls == 3u) ? 3u : (__ballot(cls == 2u) ? 2u : (__ballot(cls == 1u) ? 1u : 0u));
-        if (threadIdx.x == 0) { P.tile_class[idx] = tcls; atomicAdd(&P.tile_count[tcls], 1u); }
+        if (threadIdx.x == 0) P.tile_class[idx] = tcls;
+        n_cls[0] += tcls == 0u; n_cls[1] += tcls == 1u; n_cls[2] += tcls == 2u; n_cls[3] += tcls == 3u;
     }
+    if (threadIdx.x < 4u && n_cls[threadIdx.x]) atomicAdd(&P.tile_count[threadIdx.x], n_cls[threadIdx.x]);
 }
 __global__ void __launch_bounds__(256) hjr_order_tiles_kernel(const KParams P)
 {
     const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
-    if (idx >= P.n_owned_tiles) return;
-    const uint32_t cls = P.tile_class[idx];
-    uint32_t base = 0;
-    for (uint32_t c = 3u; c > cls; c--) base += P.tile_count[c];
-    const uint32_t pos = base + atomicAdd(&P.tile_count[4 + cls], 1u);
-    P.tile_order_w[pos] = idx * P.world + P.rank;
+    const bool live = idx < P.n_owned_tiles;
+    const uint32_t cls = live ? P.tile_class[idx] : 0xffffffffu;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t pos = 0;
+    for (uint32_t c = 0; c < 4u; c++) { // wave-aggregated scatter: one atomic per wave and class
+        const unsigned long long m = __ballot(cls == c);
+        if (m == 0ull) continue;
+        uint32_t base = 0;
+        if (lane == (uint32_t)(__ffsll((long long)m) - 1)) base = atomicAdd(&P.tile_count[4 + c], (uint32_t)__popcll(m));
+        base = (uint32_t)__shfl((int)base, __ffsll((long long)m) - 1);
+        if (cls == c) {
+            uint32_t first = 0;
+            for (uint32_t k = 3u; k > c; k--) first += P.tile_count[k];
+            pos = first + base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        }
+    }
+    if (live) P.tile_order_w[pos] = idx * P.world + P.rank;
 }
 
 // Adds the chunk sums of every owned pixel in chunk order and scales by 1/spp: a fixed summation

@@ -47,6 +47,8 @@ struct hjr_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hjr::SceneCopy scene;
     bool have_scene = false, have_frame = false;
+    std::vector<float> last_m, last_inv; // instance transforms of the frame data currently on the device
+    bool last_allow_lds = true;
     hjr::FrameData frame;
     DevBuf d_nodes, d_tri_geom, d_tri_shade, d_tri_inst, d_materials, d_lights, d_lut, d_work;
     DevBuf d_texels, d_tex_desc, d_srgb_lut, d_sky;
@@ -159,6 +161,13 @@ extern "C" int hjr_set_transforms(hjr_ctx* c, const float* m, const float* inv, 
     std::string err;
     bool allow_lds = true;
     if (const char* e = getenv("HJR_LDS_BVH")) allow_lds = atoi(e) != 0;
+    // unchanged instance transforms (static geometry, e.g. a camera-only animation): the world-space arrays and the BVH of the
+    // previous frame are still right; the reference re-uploads its IAS every frame (renderer.h:257-291), which costs it nothing
+    if (c->have_frame && c->last_allow_lds == allow_lds && c->last_m.size() == (size_t)n * 12 && n == c->scene.n_instances &&
+        (n == 0 || (memcmp(c->last_m.data(), m, (size_t)n * 48) == 0 && memcmp(c->last_inv.data(), inv, (size_t)n * 48) == 0))) {
+        if (getenv("HJR_VERBOSE")) fprintf(stderr, "[hjr] transforms unchanged: frame data reused\n");
+        return HJR_OK;
+    }
     const auto t_build0 = std::chrono::steady_clock::now();
     if (!hjr::build_frame(c->scene, m, inv, n, allow_lds, c->frame, err)) { set_error("hjr_set_transforms: " + err); return HJR_ERR_ARG; }
     const double build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_build0).count();
@@ -172,6 +181,7 @@ extern "C" int hjr_set_transforms(hjr_ctx* c, const float* m, const float* inv, 
     if (!ok) { set_error("hjr_set_transforms: device upload failed"); return HJR_ERR_DEVICE; }
     HIPCHK(hipStreamSynchronize(c->stream));
     c->have_frame = true;
+    c->last_m.assign(m, m + (size_t)n * 12); c->last_inv.assign(inv, inv + (size_t)n * 12); c->last_allow_lds = allow_lds;
     c->stats.bvh_nodes = f.n_nodes;
     c->stats.bvh_depth = f.depth;
     if (getenv("HJR_VERBOSE")) fprintf(stderr, "[hjr] BVH%u (lds_mode %d): %u nodes (%zu KB), %u triangles (%zu KB), stack %u entries/lane, host build %.1f ms\n", f.width, f.lds_mode, f.n_nodes, f.nodes.size() * 4 / 1024, f.n_tris, f.tri_geom.size() * 4 / 1024, f.stack_need, build_ms);

@@ -49,6 +49,10 @@ struct hjr_ctx {
     bool have_scene = false, have_frame = false;
     std::vector<float> last_m, last_inv; // instance transforms of the frame data currently on the device
     bool last_allow_lds = true;
+    hjr::FrameData pending; // built by hjr_prepare_transforms, made current by hjr_commit_transforms
+    std::vector<float> pending_m, pending_inv;
+    bool pending_valid = false, pending_same = false, pending_allow_lds = true;
+    double pending_build_ms = 0.0;
     hjr::FrameData frame;
     DevBuf d_nodes, d_tri_geom, d_tri_shade, d_tri_inst, d_materials, d_lights, d_lut, d_work;
     DevBuf d_texels, d_tex_desc, d_srgb_lut, d_sky;
@@ -154,39 +158,69 @@ extern "C" int hjr_upload_scene(hjr_ctx* c, const hjr_scene_view* v)
     return HJR_OK;
 }
 
-extern "C" int hjr_set_transforms(hjr_ctx* c, const float* m, const float* inv, uint32_t n)
+// updateIASMatrix + buildIAS (renderer.h:257-291, 398-490) in two halves, so that a frame loop can prepare frame f + 1 on the
+// host (worker threads, no device access, no access to what a running render reads) while frame f renders:
+//   hjr_prepare_transforms: flatten + BVH build into the context's PENDING frame data;
+//   hjr_commit_transforms:  upload the pending data (after the previous render has finished) and make it current.
+// hjr_set_transforms = prepare + commit.
+extern "C" int hjr_prepare_transforms(hjr_ctx* c, const float* m, const float* inv, uint32_t n)
 {
     if (!c || (n && (!m || !inv))) { set_error("hjr_set_transforms: null argument"); return HJR_ERR_ARG; }
     if (!c->have_scene) { set_error("hjr_set_transforms: no scene uploaded"); return HJR_ERR_STATE; }
     std::string err;
     bool allow_lds = true;
     if (const char* e = getenv("HJR_LDS_BVH")) allow_lds = atoi(e) != 0;
+    c->pending_valid = false;
+    c->pending_same = false;
     // unchanged instance transforms (static geometry, e.g. a camera-only animation): the world-space arrays and the BVH of the
     // previous frame are still right; the reference re-uploads its IAS every frame (renderer.h:257-291), which costs it nothing
-    if (c->have_frame && c->last_allow_lds == allow_lds && c->last_m.size() == (size_t)n * 12 && n == c->scene.n_instances &&
+    static const bool force_rebuild = getenv("HJR_FORCE_REBUILD") && atoi(getenv("HJR_FORCE_REBUILD")) != 0; // benchmarking knob
+    if (!force_rebuild && c->have_frame && c->last_allow_lds == allow_lds && c->last_m.size() == (size_t)n * 12 && n == c->scene.n_instances &&
         (n == 0 || (memcmp(c->last_m.data(), m, (size_t)n * 48) == 0 && memcmp(c->last_inv.data(), inv, (size_t)n * 48) == 0))) {
-        if (getenv("HJR_VERBOSE")) fprintf(stderr, "[hjr] transforms unchanged: frame data reused\n");
+        c->pending_same = true;
+        c->pending_valid = true;
         return HJR_OK;
     }
     const auto t_build0 = std::chrono::steady_clock::now();
-    if (!hjr::build_frame(c->scene, m, inv, n, allow_lds, c->frame, err)) { set_error("hjr_set_transforms: " + err); return HJR_ERR_ARG; }
-    const double build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_build0).count();
+    if (!hjr::build_frame(c->scene, m, inv, n, allow_lds, c->pending, err)) { set_error("hjr_set_transforms: " + err); return HJR_ERR_ARG; }
+    c->pending_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_build0).count();
+    c->pending_m.assign(m, m + (size_t)n * 12); c->pending_inv.assign(inv, inv + (size_t)n * 12); c->pending_allow_lds = allow_lds;
+    c->pending_valid = true;
+    return HJR_OK;
+}
+
+extern "C" int hjr_commit_transforms(hjr_ctx* c)
+{
+    if (!c) { set_error("hjr_commit_transforms: null context"); return HJR_ERR_ARG; }
+    if (!c->pending_valid) { set_error("hjr_commit_transforms: nothing prepared"); return HJR_ERR_STATE; }
+    c->pending_valid = false;
+    if (c->pending_same) {
+        if (getenv("HJR_VERBOSE")) fprintf(stderr, "[hjr] transforms unchanged: frame data reused\n");
+        return HJR_OK;
+    }
     HIPCHK(hipSetDevice(c->device));
+    std::swap(c->frame, c->pending);
     const hjr::FrameData& f = c->frame;
     bool ok = c->d_nodes.upload(f.nodes.data(), f.nodes.size() * 4, c->stream) &&
               c->d_tri_geom.upload(f.tri_geom.data(), f.tri_geom.size() * 4, c->stream) &&
               c->d_tri_shade.upload(f.tri_shade.data(), f.tri_shade.size() * 4, c->stream) &&
               c->d_tri_inst.upload(f.tri_inst.data(), f.tri_inst.size() * 4, c->stream) &&
               c->d_lights.upload(f.lights.data(), f.lights.size() * 4, c->stream);
-    if (!ok) { set_error("hjr_set_transforms: device upload failed"); return HJR_ERR_DEVICE; }
+    if (!ok) { c->have_frame = false; set_error("hjr_set_transforms: device upload failed"); return HJR_ERR_DEVICE; }
     HIPCHK(hipStreamSynchronize(c->stream));
     c->have_frame = true;
-    c->last_m.assign(m, m + (size_t)n * 12); c->last_inv.assign(inv, inv + (size_t)n * 12); c->last_allow_lds = allow_lds;
+    c->last_m.swap(c->pending_m); c->last_inv.swap(c->pending_inv); c->last_allow_lds = c->pending_allow_lds;
     c->stats.bvh_nodes = f.n_nodes;
     c->stats.bvh_depth = f.depth;
-    if (getenv("HJR_VERBOSE")) fprintf(stderr, "[hjr] BVH%u (lds_mode %d): %u nodes (%zu KB), %u triangles (%zu KB), stack %u entries/lane, host build %.1f ms\n", f.width, f.lds_mode, f.n_nodes, f.nodes.size() * 4 / 1024, f.n_tris, f.tri_geom.size() * 4 / 1024, f.stack_need, build_ms);
+    if (getenv("HJR_VERBOSE")) fprintf(stderr, "[hjr] BVH%u (lds_mode %d): %u nodes (%zu KB), %u triangles (%zu KB), stack %u entries/lane, host build %.1f ms\n", f.width, f.lds_mode, f.n_nodes, f.nodes.size() * 4 / 1024, f.n_tris, f.tri_geom.size() * 4 / 1024, f.stack_need, c->pending_build_ms);
     c->stats.n_triangles = f.n_tris;
     return HJR_OK;
+}
+
+extern "C" int hjr_set_transforms(hjr_ctx* c, const float* m, const float* inv, uint32_t n)
+{
+    const int rc = hjr_prepare_transforms(c, m, inv, n);
+    return rc != HJR_OK ? rc : hjr_commit_transforms(c);
 }
 
 extern "C" int hjr_set_lut(hjr_ctx* c, const uint8_t* rgba, int w, int h)

@@ -274,11 +274,25 @@ extern "C" int hjr_render_file(const char* render_option_json, int device)
     int cur = 0;
     const auto t_all0 = std::chrono::steady_clock::now();
     uint32_t n_frames = 0;
-    for (uint32_t frame = opt.start_frame; rc == HJR_OK && frame < opt.end_frame; frame++) {
+    // scene update of frame f + 1 (host: TRS evaluation, flatten, BVH build) runs on a helper thread while frame f renders;
+    // only its upload (hjr_commit_transforms) waits for the render.  The reference's loop is serial (renderer.h:1128-1137).
+    std::thread prep;
+    int prep_rc = HJR_OK;
+    std::string prep_err;
+    auto prepare = [&](uint32_t frame) {
         float time = frame / float(opt.fps); // renderer.h:1128
         hjr_scene_eval_transforms(scene, time, m.data(), inv.data());
-        rc = hjr_set_transforms(ctx, m.data(), inv.data(), view.n_instances);
+        prep_rc = hjr_prepare_transforms(ctx, m.data(), inv.data(), view.n_instances);
+        if (prep_rc != HJR_OK) prep_err = hjr_last_error(); // thread-local on the helper thread
+    };
+    if (opt.start_frame < opt.end_frame) prepare(opt.start_frame);
+    for (uint32_t frame = opt.start_frame; rc == HJR_OK && frame < opt.end_frame; frame++) {
+        float time = frame / float(opt.fps); // renderer.h:1128
+        if (prep.joinable()) prep.join();
+        if (prep_rc != HJR_OK) { rc = prep_rc; set_error(prep_err); break; }
+        rc = hjr_commit_transforms(ctx);
         if (rc != HJR_OK) break;
+        if (frame + 1 < opt.end_frame && !serial_io) prep = std::thread(prepare, frame + 1);
         hjr_params p;
         memset(&p, 0, sizeof(p));
         p.width = in_w; p.height = in_h;
@@ -305,13 +319,14 @@ extern "C" int hjr_render_file(const char* render_option_json, int device)
         else if (str_frame.size() < 3) str_frame = "0" + str_frame;
         sl.name = std::string(opt.image_name) + "_" + str_frame + ".png";
         n_frames++;
-        if (serial_io) { rc = write_slot(sl); if (rc != HJR_OK) set_error(write_err); }
+        if (serial_io) { rc = write_slot(sl); if (rc != HJR_OK) set_error(write_err); if (rc == HJR_OK && frame + 1 < opt.end_frame) prepare(frame + 1); }
         else {
             { std::lock_guard<std::mutex> lk(mu); sl.full = true; }
             cv.notify_all();
             cur ^= 1;
         }
     }
+    if (prep.joinable()) prep.join();
     if (!serial_io) {
         { // drain: the writer takes the slots in order, then quits
             std::unique_lock<std::mutex> lk(mu);

@@ -173,6 +173,12 @@ void hjr_destroy(hjr_ctx*);
 int hjr_upload_scene(hjr_ctx*, const hjr_scene_view*);
 /* updateIASMatrix + buildIAS — renderer.h:257-291, 398-490.  Flattens to world space and (re)builds the BVH. */
 int hjr_set_transforms(hjr_ctx*, const float* transforms12, const float* inv_transforms12, uint32_t n_instances);
+/* The same in two halves for pipelined frame loops: hjr_prepare_transforms does the host work (flatten + BVH build, worker
+ * threads) into a pending slot and touches neither the device nor anything a running render reads, so it may run on another
+ * thread while the previous frame renders; hjr_commit_transforms uploads the pending data and makes it current (call it after
+ * that render has finished).  Unchanged transforms (static geometry) are detected and cost nothing. */
+int hjr_prepare_transforms(hjr_ctx*, const float* transforms12, const float* inv_transforms12, uint32_t n_instances);
+int hjr_commit_transforms(hjr_ctx*);
 /* setLUT — renderer.h:854-898 (uchar4, normalised float read, linear, wrap).  NULL clears. */
 int hjr_set_lut(hjr_ctx*, const uint8_t* rgba, int w, int h);
 /* setSky — renderer.h:802-851: equirect float4 IBL texture (wrap, linear, element read).  NULL restores the 1x1 texel

@@ -63,6 +63,8 @@ struct hjr_ctx {
     DevBuf d_part_color, d_part_albedo, d_part_normal; // chunk sums [n_chunks][H][W] float4
     DevBuf d_spill; // overflow of the short traversal stacks (memory-path kernels)
     DevBuf d_tiles; // [tile_order | tile_class] of the cost-ordered tile list
+    DevBuf d_tile_cost; // measured per-tile cost of the previous frame
+    uint64_t cost_tag = 0; // (width, height, spp, rank, world, integrator) the costs belong to; 0 = none
     DevBuf d_dn_a, d_dn_b, d_dn_out; // denoise ping-pong / host-entry staging
     hjr_stats stats;
     bool event_pending = false;
@@ -116,7 +118,7 @@ extern "C" void hjr_destroy(hjr_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    for (DevBuf* b : { &c->d_nodes, &c->d_tri_geom, &c->d_tri_shade, &c->d_tri_inst, &c->d_materials, &c->d_lights, &c->d_lut, &c->d_spill, &c->d_tiles, &c->d_dn_a, &c->d_dn_b, &c->d_dn_out,
+    for (DevBuf* b : { &c->d_nodes, &c->d_tri_geom, &c->d_tri_shade, &c->d_tri_inst, &c->d_materials, &c->d_lights, &c->d_lut, &c->d_spill, &c->d_tiles, &c->d_tile_cost, &c->d_dn_a, &c->d_dn_b, &c->d_dn_out,
                        &c->d_texels, &c->d_tex_desc, &c->d_srgb_lut, &c->d_sky, &c->d_work, &c->d_color, &c->d_albedo, &c->d_normal, &c->d_part_color, &c->d_part_albedo, &c->d_part_normal })
         b->release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -325,7 +327,7 @@ static int render_impl(hjr_ctx* c, const hjr_params* p, void* d_color, void* d_a
     if (n_items >= 0xffffffffull) { set_error("hjr_render: image too large"); return HJR_ERR_ARG; }
 
     // work area: [0] queue head, [16..] HJR_NSTAT uint64 counters
-    const size_t work_bytes = 16 + (HJR_NSTAT + 20) * 8 + 32; // +20: phase clocks / lane-occupancy sums of the HJR_TIMING diagnostic build; +32: tile-class counters
+    const size_t work_bytes = 16 + (HJR_NSTAT + 20) * 8 + 32 + 512; // +20: phase clocks / lane-occupancy sums of the HJR_TIMING diagnostic build; +32: tile-class counters
     if (c->d_work.cap < work_bytes) {
         std::vector<unsigned char> z(work_bytes, 0);
         if (!c->d_work.upload(z.data(), work_bytes, st)) { set_error("hjr_render: work buffer allocation failed"); return HJR_ERR_DEVICE; }
@@ -396,20 +398,51 @@ static int render_impl(hjr_ctx* c, const hjr_params* p, void* d_color, void* d_a
     static const bool tile_order_on = !(getenv("HJR_TILE_ORDER") && atoi(getenv("HJR_TILE_ORDER")) == 0);
     if (tile_order_on && owned > 0) {
         const size_t tb = (size_t)owned * 4;
-        if (c->d_tiles.cap < 2 * tb) {
+        if (c->d_tiles.cap < 3 * tb) {
             c->d_tiles.release();
-            if (hipMalloc(&c->d_tiles.p, 2 * tb) != hipSuccess) { set_error("hjr_render: tile list allocation failed"); return HJR_ERR_DEVICE; }
-            c->d_tiles.cap = 2 * tb;
+            if (hipMalloc(&c->d_tiles.p, 3 * tb) != hipSuccess) { set_error("hjr_render: tile list allocation failed"); return HJR_ERR_DEVICE; }
+            c->d_tiles.cap = 3 * tb;
+            c->cost_tag = 0; // the classes of the previous frames went with the buffer
         }
         kp.n_owned_tiles = (uint32_t)owned;
         kp.tile_order_w = (uint32_t*)c->d_tiles.p;
         kp.tile_class = (uint32_t*)((char*)c->d_tiles.p + tb);
+        kp.tile_bucket = (uint32_t*)((char*)c->d_tiles.p + 2 * tb);
         kp.tile_count = (uint32_t*)((char*)c->d_work.p + 16 + (HJR_NSTAT + 20) * 8);
-        const unsigned cg = (unsigned)std::min<uint64_t>(owned, (uint64_t)c->n_cus * 16);
-        const size_t csm = (size_t)64 * kp.stack_depth * 4;
-        if (c->frame.width == 2) hipLaunchKernelGGL(hjr_classify_tiles_kernel<2>, dim3(cg), dim3(64), csm, st, kp);
-        else hipLaunchKernelGGL(hjr_classify_tiles_kernel<4>, dim3(cg), dim3(64), csm, st, kp);
-        hipLaunchKernelGGL(hjr_order_tiles_kernel, dim3((unsigned)((owned + 255) / 256)), dim3(256), 0, st, kp);
+        // Inside a class the tiles can also be ordered by what they cost in the previous frame of the same configuration.  That
+        // shortens the tail of a launch further (an 8-GPU share of C2: 19.0 -> 18.4 ms) but gives up the scanline order inside a
+        // class, which costs 1.6 % when the launch is long (N = 1: 134.6 -> 136.8 ms): used when the frame is split over several
+        // GPUs.  Pure scheduling: no pixel depends on it.  HJR_TILE_ORDER=1 / 2 force it off / on.
+        static const int order_knob = getenv("HJR_TILE_ORDER") ? atoi(getenv("HJR_TILE_ORDER")) : -1;
+        const bool cost_feedback = order_knob == 2 || (order_knob != 1 && world > 1);
+        const uint64_t tag = ((uint64_t)p->width << 48) ^ ((uint64_t)p->height << 32) ^ ((uint64_t)p->spp << 12) ^ ((uint64_t)world << 8) ^
+                             ((uint64_t)p->rank << 2) ^ (uint64_t)p->integrator ^ 0x8000000000000000ull;
+        bool have_cost = false;
+        if (cost_feedback) {
+            if (c->d_tile_cost.cap < tb) {
+                c->d_tile_cost.release();
+                if (hipMalloc(&c->d_tile_cost.p, tb) != hipSuccess) { set_error("hjr_render: tile cost allocation failed"); return HJR_ERR_DEVICE; }
+                c->d_tile_cost.cap = tb;
+                c->cost_tag = 0;
+            }
+            have_cost = c->cost_tag == tag;
+            if (!have_cost) HIPCHK(hipMemsetAsync(c->d_tile_cost.p, 0, tb, st));
+            c->cost_tag = tag;
+            kp.tile_cost = (uint32_t*)c->d_tile_cost.p;
+            kp.cost_hist = (uint32_t*)((char*)c->d_work.p + 16 + (HJR_NSTAT + 20) * 8 + 32);
+            kp.cost_div = 64u * p->spp;
+        }
+        const unsigned tg = (unsigned)((owned + 255) / 256);
+        if (have_cost) {
+            hipLaunchKernelGGL(hjr_cost_hist_kernel, dim3(tg), dim3(256), 0, st, kp);
+            hipLaunchKernelGGL(hjr_cost_scatter_kernel, dim3(tg), dim3(256), 0, st, kp);
+        } else {
+            const unsigned cg = (unsigned)std::min<uint64_t>(owned, (uint64_t)c->n_cus * 16);
+            const size_t csm = (size_t)64 * kp.stack_depth * 4;
+            if (c->frame.width == 2) hipLaunchKernelGGL(hjr_classify_tiles_kernel<2>, dim3(cg), dim3(64), csm, st, kp);
+            else hipLaunchKernelGGL(hjr_classify_tiles_kernel<4>, dim3(cg), dim3(64), csm, st, kp);
+            hipLaunchKernelGGL(hjr_order_tiles_kernel, dim3(tg), dim3(256), 0, st, kp);
+        }
         HIPCHK(hipGetLastError());
         kp.tile_order = (const uint32_t*)c->d_tiles.p;
     }

@@ -52,6 +52,10 @@ struct KParams {
     uint32_t* tile_class;            // per owned tile: costliest first hit of its pixel centres: 0 background / light, 1 Disney, 2 metallic (msGGX), 3 glass
     uint32_t* tile_count;            // [0..3] tiles per class, [4..7] scatter cursors
     uint32_t n_owned_tiles;
+    uint32_t* tile_bucket;           // per owned tile: sort key of the measured-cost order
+    uint32_t* tile_cost;             // per owned tile: closest-hit rays traced for it this frame (feeds the next frame's tile order)
+    uint32_t* cost_hist;             // [0..63] tiles per cost bucket, [64..127] scatter cursors
+    uint32_t cost_div;               // 64 * spp: rays per tile at one ray per sample
     uint32_t spill_stride;           // lanes in the grid
     float4* part_color;              // [n_chunks][height][width] chunk sums when n_chunks > 1
     float4* part_albedo;
@@ -1068,6 +1072,7 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
     uint32_t item = 0;          // px | py << 13 | chunk << 26
     uint32_t s = 0;
     uint32_t w_next = 0, w_end = 0; // this wave's private item range (wave-uniform)
+    uint32_t it_cost = 0;           // closest-hit rays traced for the current item
     f3 sumL = V1(0.0f), sumA = V1(0.0f), sumN = V1(0.0f);
     f3 sh_d = V1(0.0f), sh_contrib = V1(0.0f);
     float sh_tmax = 0.0f;
@@ -1173,12 +1178,28 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
                     w_next = base + (n - have);
                     w_end = base + 64u;
                 } else w_next += n;
+                // measured cost of a tile (orders the tiles of the next frame, hjr_cost_hist_kernel): a lane sums the rays of its
+                // consecutive items of one tile and flushes when it moves on; lanes leaving the same tile together (the usual
+                // case) share one atomic.  All lanes are here (m is wave-uniform), so the shuffles below are well defined.
+                const uint32_t old_tile = (HJR_PY / HJR_TILE) * P.tiles_x + HJR_PX / HJR_TILE;
+                uint32_t new_tile = 0xffffffffu;
+                if (need && q < P.n_owned_items) new_tile = P.tile_order ? P.tile_order[(q >> 6) / P.n_chunks] : ((q >> 6) / P.n_chunks) * P.world + P.rank;
+                bool flush = need && P.tile_cost && it_cost != 0u && new_tile != old_tile;
+                while (__ballot(flush)) {
+                    const int leader = __ffsll((long long)__ballot(flush)) - 1;
+                    const uint32_t t = (uint32_t)__shfl((int)old_tile, leader);
+                    const bool mine = flush && old_tile == t;
+                    uint32_t v = mine ? it_cost : 0u;
+                    for (int off = 32; off > 0; off >>= 1) v += (uint32_t)__shfl_xor((int)v, off);
+                    if ((int)lane == leader) atomicAdd(&P.tile_cost[t / P.world], v);
+                    if (mine) { it_cost = 0u; flush = false; }
+                }
                 if (need) {
                     if (q < P.n_owned_items) {
                         // item q = ((owned tile * n_chunks) + chunk) * 64 + pixel-in-tile: the 64 lanes of a wave start on one
                         // tile and one sample chunk (coherent primary rays)
                         const uint32_t tc = q >> 6;
-                        const uint32_t tile = P.tile_order ? P.tile_order[tc / P.n_chunks] : (tc / P.n_chunks) * P.world + P.rank;
+                        const uint32_t tile = new_tile;
                         const uint32_t chunk = tc % P.n_chunks;
                         const uint32_t tx = tile % P.tiles_x, ty = tile / P.tiles_x;
                         const uint32_t px = tx * HJR_TILE + (q & 7u);
@@ -1242,6 +1263,7 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
         HJR_TICKX(1)
 
         if (tracing) {
+            it_cost++;
             HitInfo prd;
             hit_program<STATS, AOVS>(P, tris, mats, h, ps.rd, prd, lc);
             HJR_TICKX(2)
@@ -1449,6 +1471,48 @@ __global__ void __launch_bounds__(256) hjr_order_tiles_kernel(const KParams P)
         }
     }
     if (live) P.tile_order_w[pos] = idx * P.world + P.rank;
+}
+
+// From the second frame of a sequence on, the tiles are ordered by what they actually cost in the previous frame (closest-hit
+// rays per sample) inside their first-hit class: a counting sort over 64 keys in two kernels; the order inside a key is arbitrary.
+HD uint32_t cost_bucket(uint32_t cls, uint32_t cost, uint32_t cost_div)
+{
+    // key = (first-hit class, measured rays per sample in steps of 1/2): the class keeps waves of like materials together in
+    // time (3 % at N = 1), the cost orders the tiles inside a class so that the last items of a class are its cheapest
+    const uint32_t b = (uint32_t)(((unsigned long long)cost * 2ull) / cost_div);
+    return (cls & 3u) * 16u + (b > 15u ? 15u : b);
+}
+__global__ void __launch_bounds__(256) hjr_cost_hist_kernel(const KParams P)
+{
+    __shared__ uint32_t h[64];
+    if (threadIdx.x < 64u) h[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
+    if (idx < P.n_owned_tiles) {
+        const uint32_t b = cost_bucket(P.tile_class[idx], P.tile_cost[idx], P.cost_div);
+        P.tile_bucket[idx] = b;
+        atomicAdd(&h[b], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 64u && h[threadIdx.x]) atomicAdd(&P.cost_hist[threadIdx.x], h[threadIdx.x]);
+}
+__global__ void __launch_bounds__(256) hjr_cost_scatter_kernel(const KParams P)
+{
+    __shared__ uint32_t h[64], base[64];
+    if (threadIdx.x < 64u) h[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
+    const bool live = idx < P.n_owned_tiles;
+    uint32_t b = 0, rank_in_block = 0;
+    if (live) { b = P.tile_bucket[idx]; rank_in_block = atomicAdd(&h[b], 1u); P.tile_cost[idx] = 0u; } // zeroed for this frame's sums
+    __syncthreads();
+    if (threadIdx.x < 64u) {
+        uint32_t first = 0;
+        for (uint32_t k = 63u; k > threadIdx.x; k--) first += P.cost_hist[k]; // expensive buckets first
+        base[threadIdx.x] = h[threadIdx.x] ? first + atomicAdd(&P.cost_hist[64u + threadIdx.x], h[threadIdx.x]) : 0u;
+    }
+    __syncthreads();
+    if (live) P.tile_order_w[base[b] + rank_in_block] = idx * P.world + P.rank;
 }
 
 // Adds the chunk sums of every owned pixel in chunk order and scales by 1/spp: a fixed summation

@@ -106,6 +106,22 @@ def test_tile_sharding_is_exact(cornell, dev):
     assert_bitexact(acc, full, "sum of shards")
 
 
+def test_tile_order_is_pure_scheduling(cornell, dev):
+    """The order in which tiles are handed out (first-hit classes; from the second frame of a multi-GPU share on also the cost
+    measured in the previous frame) must not change a single bit: repeated renders of one share are identical."""
+    w, h, spp, R = 264, 152, 20, 4
+    ref, _, _ = dev.render(cornell.hjr_params(w, h, spp), want_aovs=False)
+    for r in (0, 3):
+        p = cornell.hjr_params(w, h, spp, rank=r, world_size=R)
+        first, _, _ = dev.render(p, want_aovs=False)    # class order (no history for this configuration)
+        second, _, _ = dev.render(p, want_aovs=False)   # class + measured cost
+        third, _, _ = dev.render(p, want_aovs=False)
+        assert_bitexact(second, first, "second frame of share %d" % r)
+        assert_bitexact(third, first, "third frame of share %d" % r)
+        mask = hjr.owned_tile_mask(w, h, r, R)
+        assert_bitexact(first[mask], ref[mask], "share %d vs full frame" % r)
+
+
 def test_ragged_sizes(cornell, dev, oracle):
     for (w, h) in [(1, 1), (7, 5), (9, 17)]:
         c, _, _ = dev.render(cornell.hjr_params(w, h, 2))

@@ -24,7 +24,9 @@
  *   q0 = lo.x[0..3]  q1 = hi.x[0..3]  q2 = lo.y[0..3]  q3 = hi.y[0..3]  q4 = lo.z[0..3]  q5 = hi.z[0..3]  q6 = child refs[0..3]
  *   A ray picks its near/far plane rows by the sign of its direction, so the slab test needs no min/max.
  *   Unused child slots: inverted box (+1e30 / -1e30) and an empty-leaf ref. */
+#ifndef HJR_NODE2_F4
 #define HJR_NODE2_F4 4
+#endif
 /* HJR_BVH4_QUANT=1 (experiment, off by default): BVH4 node in 64 B = 4 x float4, child planes as 8-bit offsets from the
  * node's own box (rounded outwards, so every child box only grows; a conservative BVH cannot change a result):
  *   q0 = (org.x org.y org.z scale.x)  q1 = (scale.y scale.z lo.x[4 bytes] hi.x[4 bytes])

@@ -294,7 +294,7 @@ void emit_bvh2(const Builder& B, FrameData& out)
     for (size_t i = 0; i < B.nodes.size(); i++)
         if (B.nodes[i].left >= 0) inner_id[i] = (int)n_inner++;
     if (n_inner == 0) {
-        out.nodes.assign(16, 0.0f);
+        out.nodes.assign((size_t)HJR_NODE2_F4 * 4, 0.0f);
         const BuildNode& r = B.nodes[0];
         float* q = out.nodes.data();
         for (int c = 0; c < 2; c++)
@@ -305,12 +305,12 @@ void emit_bvh2(const Builder& B, FrameData& out)
         out.stack_need = 2;
         return;
     }
-    out.nodes.assign((size_t)n_inner * 16, 0.0f);
+    out.nodes.assign((size_t)n_inner * HJR_NODE2_F4 * 4, 0.0f);
     out.n_nodes = n_inner;
     out.stack_need = B.max_depth + 2;
     for (size_t i = 0; i < B.nodes.size(); i++) {
         if (inner_id[i] < 0) continue;
-        float* q = &out.nodes[(size_t)inner_id[i] * 16];
+        float* q = &out.nodes[(size_t)inner_id[i] * HJR_NODE2_F4 * 4];
         const int cid[2] = { B.nodes[i].left, B.nodes[i].right };
         for (int c = 0; c < 2; c++) {
             const BuildNode& ch = B.nodes[(size_t)cid[c]];

@@ -1411,7 +1411,7 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
     }
 }
 
-// ---- cost-ordered tile list.  The frame ends when the slowest work item ends, and an item (16 samples of one pixel, each up
+// ---- cost-ordered tile list.  The frame ends when the slowest work item ends, and an item (8 samples of one pixel, each up
 // to 10 bounces, strictly sequential) can run for milliseconds: with plain scanline order the tail of the launch is whatever
 // the last tiles happen to cost (5 ms on a 64 x 64 frame, 15 % of an 18 ms launch when the frame is split over 8 GPUs).
 // One wave per owned tile casts the 64 pixel-centre rays (no RNG), classifies the tile by its costliest first hit

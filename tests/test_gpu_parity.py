@@ -156,7 +156,7 @@ def test_full_size_properties(cornell, dev):
 
 
 def test_c5_shard_3840x2160_4096spp(cornell, dev):
-    """BASELINE configs[4] exactly as one of its 8 ranks runs it: 3840x2160, 4096 spp (16 chunks of 256 samples), rank 3 of 8.
+    """BASELINE configs[4] exactly as one of its 8 ranks runs it: 3840x2160, 4096 spp (64 runs of 64 samples), rank 3 of 8.
     An owned window is compared with the oracle; un-owned pixels stay zero."""
     w, h, spp, R, r = 3840, 2160, 4096, 8, 3
     tiles_x = w // 8

@@ -545,23 +545,6 @@ HD f3 crossf(f3 a, f3 b)
     return V(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
 }
 // canonical ray/triangle test — the same operation sequence as the oracle's ray_tri()
-#ifdef HJR_BRANCHLESS_TRI
-HD bool ray_tri(f3 v0, f3 v1, f3 v2, f3 o, f3 d, float tmin, float tmax, float& t, float& b1, float& b2)
-{
-    const f3 e1 = v1 - v0, e2 = v2 - v0;
-    const f3 p = crossf(d, e2);
-    const float det = dotf(e1, p);
-    const float inv = 1.0f / det;
-    const f3 tv = o - v0;
-    const float u = dotf(tv, p) * inv;
-    const f3 q = crossf(tv, e1);
-    const float v = dotf(d, q) * inv;
-    const float tt = dotf(e2, q) * inv;
-    const bool ok = (det != 0.0f) & (u >= 0.0f) & (u <= 1.0f) & (v >= 0.0f) & (u + v <= 1.0f) & (tt > tmin) & (tt < tmax);
-    t = tt; b1 = u; b2 = v;
-    return ok;
-}
-#else
 HD bool ray_tri(f3 v0, f3 v1, f3 v2, f3 o, f3 d, float tmin, float tmax, float& t, float& b1, float& b2)
 {
     f3 e1 = v1 - v0, e2 = v2 - v0;
@@ -580,7 +563,6 @@ HD bool ray_tri(f3 v0, f3 v1, f3 v2, f3 o, f3 d, float tmin, float tmax, float& 
     t = tt; b1 = u; b2 = v;
     return true;
 }
-#endif
 
 // ---- per-lane traversal stack in LDS, element i of this lane at stack[i * BLOCK] (conflict-free columns).  Small scenes that
 // are staged into LDS use 16-bit entries (node index < 32768, or leaf: bit15 | count << 13 | first triangle < 8192), which
@@ -667,19 +649,6 @@ HD uint32_t node_step(const float4* nodes, uint32_t& cur, const BoxRay& R, float
     lo1 = fmaxf(lo1, tmin); hi1 = fminf(hi1, tfar);
     const bool h0 = lo0 <= hi0, h1 = lo1 <= hi1; // conservative through the 2^-15 box padding (>= 16x the rounding error of t)
     const uint32_t c0 = f2bits(q3.x), c1 = f2bits(q3.y);
-#ifdef HJR_BRANCHLESS_NODE
-    const bool both = h0 & h1, any = h0 | h1;
-    const bool swap = lo1 < lo0;
-    const uint32_t nearc = both ? (swap ? c1 : c0) : (h0 ? c0 : c1);
-    if (both) stack.put(sp, swap ? c0 : c1);
-    sp += both ? 1 : 0;
-    uint32_t popped = HJR_TRAV_DONE;
-    const bool do_pop = !any & (sp > 0);
-    if (do_pop) popped = stack.get(sp - 1);
-    sp -= do_pop ? 1 : 0;
-    cur = any ? nearc : popped;
-    return 2u;
-#else
     if (h0 && h1) {
         const bool swap = lo1 < lo0;
         stack.put(sp, swap ? c0 : c1);
@@ -690,29 +659,10 @@ HD uint32_t node_step(const float4* nodes, uint32_t& cur, const BoxRay& R, float
     else if (sp > 0) { sp--; cur = stack.get(sp); }
     else cur = HJR_TRAV_DONE;
     return 2u;
-#endif
     } else {
     const float4* nd = nodes + cur * HJR_NODE4_F4;
     const f3 inv = R.inv, oi = R.oi;
     const float INF = bits2f(0x7f800000u);
-#if HJR_BVH4_QUANT
-    const float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], rr = nd[3];
-    // t = ((org + byte * scale) - o) / d  ==  byte * (scale * inv) + (org * inv + oi); near / far plane words by direction sign
-    const float ax = q0.w * inv.x, ay = q1.x * inv.y, az = q1.y * inv.z;
-    const float bx = fmaf(q0.x, inv.x, oi.x), by = fmaf(q0.y, inv.y, oi.y), bz = fmaf(q0.z, inv.z, oi.z);
-    const uint32_t nx = f2bits(R.sx ? q1.w : q1.z), fx = f2bits(R.sx ? q1.z : q1.w);
-    const uint32_t ny = f2bits(R.sy ? q2.y : q2.x), fy = f2bits(R.sy ? q2.x : q2.y);
-    const uint32_t nz = f2bits(R.sz ? q2.w : q2.z), fz = f2bits(R.sz ? q2.z : q2.w);
-#define HJR_UB(w, C) ((float)(((w) >> (8 * C)) & 0xffu))
-#define HJR_CHILD(C)                                                                                                                  \
-    float tn##C = fmaxf(fmaxf(fmaf(HJR_UB(nx, C), ax, bx), fmaf(HJR_UB(ny, C), ay, by)), fmaxf(fmaf(HJR_UB(nz, C), az, bz), tmin)); \
-    const float tf##C = fminf(fminf(fmaf(HJR_UB(fx, C), ax, bx), fmaf(HJR_UB(fy, C), ay, by)), fminf(fmaf(HJR_UB(fz, C), az, bz), tfar)); \
-    const bool h##C = tn##C <= tf##C;                                                                                                 \
-    tn##C = h##C ? tn##C : INF;
-    HJR_CHILD(0) HJR_CHILD(1) HJR_CHILD(2) HJR_CHILD(3)
-#undef HJR_CHILD
-#undef HJR_UB
-#else
     // near / far plane rows picked by the ray's direction signs: no min/max per axis
     const float4 nx = nd[0 + R.sx], fx = nd[1 - R.sx];
     const float4 ny = nd[2 + R.sy], fy = nd[3 - R.sy];
@@ -725,7 +675,6 @@ HD uint32_t node_step(const float4* nodes, uint32_t& cur, const BoxRay& R, float
     tn##C = h##C ? tn##C : INF;
     HJR_CHILD(x, 0) HJR_CHILD(y, 1) HJR_CHILD(z, 2) HJR_CHILD(w, 3)
 #undef HJR_CHILD
-#endif
     const uint32_t r0 = f2bits(rr.x), r1 = f2bits(rr.y), r2 = f2bits(rr.z), r3 = f2bits(rr.w);
     const float m = fminf(fminf(tn0, tn1), fminf(tn2, tn3));
     // nearest hit child first (ties: lowest slot); the other hit children are pushed in slot order

@@ -27,21 +27,7 @@
 #ifndef HJR_NODE2_F4
 #define HJR_NODE2_F4 4
 #endif
-/* HJR_BVH4_QUANT=1 (experiment, off by default): BVH4 node in 64 B = 4 x float4, child planes as 8-bit offsets from the
- * node's own box (rounded outwards, so every child box only grows; a conservative BVH cannot change a result):
- *   q0 = (org.x org.y org.z scale.x)  q1 = (scale.y scale.z lo.x[4 bytes] hi.x[4 bytes])
- *   q2 = (lo.y[4] hi.y[4] lo.z[4] hi.z[4])  q3 = child refs[0..3];   plane = org + byte * scale, byte c of a word = child c.
- *   Unused child slots: lo byte 255, hi byte 0 and an empty-leaf ref.
- * Parity-green, but 7 % slower on the 1 M-triangle scene: 43 % fewer node bytes do not pay for the decode instructions and
- * the looser boxes (+21 % triangle tests) - that kernel is not bound by bytes (profiles/r01_experiments.md). */
-#ifndef HJR_BVH4_QUANT
-#define HJR_BVH4_QUANT 0
-#endif
-#if HJR_BVH4_QUANT
-#define HJR_NODE4_F4 4
-#else
 #define HJR_NODE4_F4 7
-#endif
 #define HJR_BLOCK_LDS 1024          /* threads of the one-per-CU workgroup that shares an LDS copy of the BVH (16 waves = 4 per SIMD) */
 #define HJR_LDS_BUDGET (159u * 1024u)
 /* Triangle (leaf order), 48 B = 3 x float4: world-space vertices + global prim id.

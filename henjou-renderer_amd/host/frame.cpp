@@ -353,49 +353,6 @@ void emit_bvh4(const Builder& B, FrameData& out)
             if (B.nodes[(size_t)wide[head].child[c]].left >= 0) make_wide(wide[head].child[c]);
     out.n_nodes = (uint32_t)wide.size();
     out.nodes.assign(wide.size() * (size_t)HJR_NODE4_F4 * 4, 0.0f);
-#if HJR_BVH4_QUANT
-    for (size_t i = 0; i < wide.size(); i++) {
-        float* q = &out.nodes[i * (size_t)HJR_NODE4_F4 * 4];
-        uint32_t planes[6] = { 0xffffffffu, 0u, 0xffffffffu, 0u, 0xffffffffu, 0u }; // lo.x hi.x lo.y hi.y lo.z hi.z; unused slots: lo 255, hi 0
-        for (int a = 0; a < 3; a++) {
-            double lo = 1e300, hi = -1e300;
-            for (int c = 0; c < wide[i].n; c++) {
-                const BuildNode& ch = B.nodes[(size_t)wide[i].child[c]];
-                lo = std::min(lo, (double)ch.box.lo[a]); hi = std::max(hi, (double)ch.box.hi[a]);
-            }
-            const float org = (float)lo; // the minimum of floats is a float
-            float sc = (float)((hi - lo) / 255.0);
-            if (!(sc > 0.0f)) sc = 1e-30f;
-            for (;;) { // smallest scale (up to a few ulp) whose 8-bit grid covers the node and encloses every child box
-                bool ok = (double)org + 255.0 * (double)sc >= hi;
-                uint32_t wlo = 0xffffffffu, whi = 0u;
-                for (int c = 0; ok && c < wide[i].n; c++) {
-                    const BuildNode& ch = B.nodes[(size_t)wide[i].child[c]];
-                    double ql = std::floor(((double)ch.box.lo[a] - (double)org) / (double)sc);
-                    double qh = std::ceil(((double)ch.box.hi[a] - (double)org) / (double)sc);
-                    ql = std::min(std::max(ql, 0.0), 255.0); qh = std::min(std::max(qh, 0.0), 255.0);
-                    // containment in exact arithmetic (org, sc and the bytes are exact in double)
-                    if ((double)org + ql * (double)sc > (double)ch.box.lo[a]) ql -= 1.0;
-                    if ((double)org + qh * (double)sc < (double)ch.box.hi[a]) qh += 1.0;
-                    if (ql < 0.0 || qh > 255.0) { ok = false; break; }
-                    wlo = (wlo & ~(0xffu << (8 * c))) | ((uint32_t)ql << (8 * c));
-                    whi = (whi & ~(0xffu << (8 * c))) | ((uint32_t)qh << (8 * c));
-                }
-                if (ok) { planes[2 * a] = wlo; planes[2 * a + 1] = whi; break; }
-                sc = std::nextafterf(sc, std::numeric_limits<float>::infinity());
-            }
-            q[a] = org;
-            q[3 + a] = sc;
-        }
-        for (int k = 0; k < 6; k++) q[6 + k] = u2f(planes[k]);
-        for (int c = 0; c < 4; c++) {
-            if (c < wide[i].n) {
-                const BuildNode& ch = B.nodes[(size_t)wide[i].child[c]];
-                q[12 + c] = u2f(ch.left >= 0 ? (uint32_t)wide_of[(size_t)wide[i].child[c]] : leaf_ref(ch.first, ch.count));
-            } else q[12 + c] = u2f(leaf_ref(0, 0));
-        }
-    }
-#else
     parallel_chunks(wide.size(), 8192, [&](size_t ib, size_t ie, size_t) {
     for (size_t i = ib; i < ie; i++) {
         float* q = &out.nodes[i * (size_t)HJR_NODE4_F4 * 4];
@@ -411,7 +368,6 @@ void emit_bvh4(const Builder& B, FrameData& out)
         }
     }
     });
-#endif
     // exact worst-case traversal stack: every visited wide node can leave (children - 1) entries pending
     std::vector<uint32_t> pend(wide.size(), 0);
     uint32_t worst = 1;
@@ -541,15 +497,10 @@ bool build_frame(const SceneCopy& sc, const float* M, const float* Mi, uint32_t 
     if (n == 0) { // empty scene: one BVH4 root with four empty slots
         out.width = 4; out.lds_mode = 0;
         out.nodes.assign((size_t)HJR_NODE4_F4 * 4, 0.0f);
-#if HJR_BVH4_QUANT
-        for (int a = 0; a < 3; a++) { out.nodes[3 + a] = 1.0f; out.nodes[6 + 2 * a] = u2f(0xffffffffu); out.nodes[7 + 2 * a] = u2f(0u); }
-        for (int c = 0; c < 4; c++) out.nodes[12 + c] = u2f(leaf_ref(0, 0));
-#else
         for (int c = 0; c < 4; c++) {
             for (int a = 0; a < 3; a++) { out.nodes[8 * a + c] = 1e30f; out.nodes[8 * a + 4 + c] = -1e30f; }
             out.nodes[24 + c] = u2f(leaf_ref(0, 0));
         }
-#endif
         out.n_nodes = 1;
         out.stack_need = 2;
         return true;

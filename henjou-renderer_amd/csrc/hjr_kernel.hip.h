@@ -3,831 +3,26 @@
 //   multiple-scattering GGX) -> next-event-estimation integrator (also Pathtrace / MIS).
 //
 // Execution model
-//   * one lane owns one pixel and runs its `spp` samples in order, so the per-pixel fp32 sum has a fixed order
-//     (bitwise independent of scheduling, tile sharding and GPU count);
-//   * wavefronts are persistent: a lane whose pixel is finished pulls the next pixel from a global queue with one
-//     wave-aggregated atomic (ballot + mbcnt prefix) — the ray queue never drains until the frame is done;
+//   * a work item is one pixel's run of 8 consecutive samples, executed in order by one lane, so every per-pixel fp32 sum has
+//     a fixed order (bitwise independent of scheduling, tile sharding and GPU count);
+//   * wavefronts are persistent: a wave takes 64 items at a time from a global queue with one atomic and hands them to its
+//     idle lanes with ballot + mbcnt prefix sums; tiles are queued expensive first (cost-ordered tile list);
 //   * paths are regenerated in place: a lane whose path ended (Russian roulette, miss, light hit, depth cap)
-//     starts its next sample in the same loop iteration, so every trace call runs with (nearly) full waves;
-//   * the traversal stack is per lane in LDS ([level][lane] -> conflict-free ds_read/ds_write_b32);
+//     starts its next sample in the same loop iteration, so every trace runs with (nearly) full waves;
+//   * the NEE shadow ray of a bounce is traced fused with the next closest-hit ray; slow lanes carry their traversal over
+//     to the next round instead of holding the wave;
+//   * the traversal stack is per lane in LDS ([level][lane] -> conflict-free ds_read/ds_write_b32); small scenes keep the
+//     whole BVH2, the triangles and the material / light tables in LDS as well;
 //   * nodes / triangles / shading records / materials / lights are 16-byte-record arrays fetched as dwordx4.
+// Headers: hjr_params (KParams), hjr_sampling (CMJ, frames), hjr_bsdf (materials), hjr_traverse (ray traversal), this file
+// (hit programs, light sampling, the megakernel, tile pre-pass, finalize).
 //
 // Each device function cites the reference lines it restates (paths relative to the reference's include/).
 #pragma once
-#include <type_traits>
-
-#include "hjr_layout.h"
-#include "hjr_math.hip.h"
-
-struct KParams {
-    const float4* nodes;
-    const float4* tri_geom;
-    const float4* tri_shade;
-    const uint32_t* tri_inst;
-    const float4* materials;
-    const float4* lights;
-    const uchar4* lut;
-    const uchar4* texels;    // RGBA8 atlas of all material textures
-    const uint4* tex_desc;   // per texture slot: (texel offset, width, height, srgb)
-    const float* srgb_lut;   // 256-entry sRGB -> linear table (host-computed)
-    const float4* sky_tex;   // equirect IBL (float4), null = constant sky
-    float4* aov_color;
-    float4* aov_albedo;
-    float4* aov_normal;
-    unsigned int* queue_head;
-    unsigned long long* stats;
-    int lut_w, lut_h;
-    int sky_w, sky_h;
-    uint32_t n_lights;
-    uint32_t width, height, spp, frame, seed, integrator;
-    uint32_t tiles_x, n_owned_items; // items = owned tiles * n_chunks * 64
-    uint32_t rank, world;
-    uint32_t chunk_spp, n_chunks;    // samples per work item, work items per pixel (hjr_chunking)
-    uint32_t n_node_f4, n_tri_f4;    // float4 counts of nodes[] / tri_geom[] (LDS staging)
-    uint32_t n_mat_f4, n_light_f4;   // float4 counts of materials[] / lights[] (staged behind the triangles in the LDS variant)
-    uint32_t stack_depth;            // traversal stack entries per lane (BVH depth + 1)
-    uint32_t* stack_spill;           // memory-path kernels: overflow of the short LDS stacks, [level][lane]
-    const uint32_t* tile_order;      // owned tiles, expensive first (hjr_classify_tiles_kernel); null = plain round-robin order
-    uint32_t* tile_order_w;          // the same buffer, writable (pre-pass kernels)
-    uint32_t* tile_class;            // per owned tile: costliest first hit of its pixel centres: 0 background / light, 1 Disney, 2 metallic (msGGX), 3 glass
-    uint32_t* tile_count;            // [0..3] tiles per class, [4..7] scatter cursors
-    uint32_t n_owned_tiles;
-    uint32_t* tile_bucket;           // per owned tile: sort key of the measured-cost order
-    uint32_t* tile_cost;             // per owned tile: closest-hit rays traced for it this frame (feeds the next frame's tile order)
-    uint32_t* cost_hist;             // [0..63] tiles per cost bucket, [64..127] scatter cursors
-    uint32_t cost_div;               // 64 * spp: rays per tile at one ray per sample
-    uint32_t spill_stride;           // lanes in the grid
-    float4* part_color;              // [n_chunks][height][width] chunk sums when n_chunks > 1
-    float4* part_albedo;
-    float4* part_normal;
-    float cam_pos[3], cam_dir[3], cam_up[3], cam_right[3];
-    float cam_f;
-    float sky[3]; // scene_sky_default * ibl_intensity
-    float ibl_intensity;
-};
-
-// ------------------------------------------------------------------ kernel/cmj.h
-struct CMJState { unsigned long long n_spp; uint32_t scramble, depth, image_idx; }; // cmj.h:53-58
-
-HD uint32_t xxhash32_u4(uint32_t px, uint32_t py, uint32_t pz, uint32_t pw) // cmj.h:38-51
-{
-    const uint32_t P2 = 2246822519U, P3 = 3266489917U, P4 = 668265263U, P5 = 374761393U;
-    uint32_t h = pw + P5 + px * P3;
-    h = P4 * ((h << 17) | (h >> 15));
-    h += py * P3;
-    h = P4 * ((h << 17) | (h >> 15));
-    h += pz * P3;
-    h = P4 * ((h << 17) | (h >> 15));
-    h = P2 * (h ^ (h >> 15));
-    h = P3 * (h ^ (h >> 13));
-    return h ^ (h >> 16);
-}
-HD uint32_t cmj_permute(uint32_t i, uint32_t l, uint32_t p) // cmj.h:60-91
-{
-    uint32_t w = l - 1;
-    w |= w >> 1; w |= w >> 2; w |= w >> 4; w |= w >> 8; w |= w >> 16;
-    do {
-        i ^= p; i *= 0xe170893d;
-        i ^= p >> 16;
-        i ^= (i & w) >> 4;
-        i ^= p >> 8; i *= 0x0929eb3f;
-        i ^= p >> 23;
-        i ^= (i & w) >> 1; i *= 1 | p >> 27;
-        i *= 0x6935fa69;
-        i ^= (i & w) >> 11; i *= 0x74dcb303;
-        i ^= (i & w) >> 2; i *= 0x9e501cc3;
-        i ^= (i & w) >> 2; i *= 0xc860a3df;
-        i &= w;
-        i ^= i >> 5;
-    } while (i >= l);
-    return (i + p) % l;
-}
-HD float cmj_randfloat(uint32_t i, uint32_t p) // cmj.h:93-106
-{
-    i ^= p;
-    i ^= i >> 17; i ^= i >> 10; i *= 0xb36534e5;
-    i ^= i >> 12; i ^= i >> 21; i *= 0x93fc4795;
-    i ^= 0xdf6e307f;
-    i ^= i >> 17; i *= 1 | p >> 18;
-    return i * (1.0f / 4294967808.0f);
-}
-HD f2 cmj(uint32_t index, uint32_t scramble) // cmj.h:108-117
-{
-    index = cmj_permute(index, 16, scramble * 0x51633e2d);
-    uint32_t sx = cmj_permute(index % 4, 4, scramble * 0xa511e9b3);
-    uint32_t sy = cmj_permute(index / 4, 4, scramble * 0x63d83595);
-    float jx = cmj_randfloat(index, scramble * 0xa399d265);
-    float jy = cmj_randfloat(index, scramble * 0x711ad6a5);
-    f2 r;
-    r.x = (index % 4 + (sy + jx) / 4) / 4;
-    r.y = (index / 4 + (sx + jy) / 4) / 4;
-    return r;
-}
-HD f2 cmj_2d(CMJState& st) // cmj.h:119-128
-{
-    const uint32_t index = (uint32_t)(st.n_spp % 16);
-    const uint32_t scramble = xxhash32_u4((uint32_t)(st.n_spp / 16), st.image_idx, st.depth, st.scramble);
-    f2 r = cmj(index, scramble);
-    st.depth++;
-    return r;
-}
-HD float cmj_1d(CMJState& st) { return cmj_2d(st).x; } // cmj.h:130-133
-
-// ------------------------------------------------------------------ kernel/math.h
-HD f3 schlick3(f3 F0, f3 w, f3 n) // math.h:26-29
-{
-    float term1 = 1.0f - dot(w, n);
-    return ssub(1.0f, F0) * p_pow5(term1) + F0;
-}
-HD float schlick_ior(float no, float ni, f3 w, f3 n) // math.h:31-37
-{
-    float F0 = (no - ni) / (no + ni);
-    F0 = F0 * F0;
-    float term1 = 1.0f - dot(w, n);
-    return F0 + (1.0f - F0) * p_pow5(term1);
-}
-HD void orthonormal_basis(f3 n, f3& t, f3& b) // math.h:43-51
-{
-    float sign = copysignf(1.0f, n.z);
-    const float a = -1.0f / (sign + n.z);
-    const float bb = n.x * n.y * a;
-    t = V(1.0f + sign * n.x * n.x * a, sign * bb, -sign * n.x);
-    b = V(bb, sign + n.y * n.y * a, -n.y);
-}
-HD f3 world_to_local(f3 v, f3 t, f3 n, f3 b) { return V(dot(v, t), dot(v, n), dot(v, b)); } // math.h:53-59
-HD f3 local_to_world(f3 v, f3 t, f3 n, f3 b) // math.h:61-71
-{
-    return V(v.x * t.x + v.y * n.x + v.z * b.x, v.x * t.y + v.y * n.y + v.z * b.y, v.x * t.z + v.y * n.z + v.z * b.z);
-}
-HD float norm2(f3 v) { return v.x * v.x + v.y * v.y + v.z * v.z; } // math.h:88-90
-HD bool refract3(f3 v, f3 n, float ior1, float ior2, f3& r) // math.h:92-103
-{
-    const f3 t_h = (v - n * dot(v, n)) * (-ior1 / ior2);
-    if (norm2(t_h) > 1.0f) return false;
-    const f3 t_p = n * (-sqrtf(fmaxf(1.0f - norm2(t_h), 0.0f)));
-    r = t_h + t_p;
-    return true;
-}
-
-// ------------------------------------------------------------------ surface record: the fields of Payload the BSDFs read
-struct Surface { // kernel/Payload.h:12-42
-    f3 basecolor;
-    float metallic, roughness, sheen, clearcoat, ior;
-    bool is_specular, is_thinfilm;
-};
-
-// ------------------------------------------------------------------ thin-film LUT: tex2D<float4>(params.lut_texture, u, v), disneyBRDF.h:11-14
-// Sampler state from renderer.h:854-898 (uchar4 -> normalised float, linear, wrap, normalised coords); filtering per the
-// CUDA programming guide: texel-centre offset, 1.8 fixed-point weights.
-HD f3 lut_fetch(const KParams& P, float u, float v)
-{
-    if (!P.lut || P.lut_w <= 0 || P.lut_h <= 0) return V1(0.0f);
-    int w = P.lut_w, h = P.lut_h;
-    float x = u * (float)w - 0.5f, y = v * (float)h - 0.5f;
-    float fx = floorf(x), fy = floorf(y);
-    float ax = floorf((x - fx) * 256.0f + 0.5f) * (1.0f / 256.0f);
-    float ay = floorf((y - fy) * 256.0f + 0.5f) * (1.0f / 256.0f);
-    int i0 = (int)fx % w; if (i0 < 0) i0 += w;
-    int j0 = (int)fy % h; if (j0 < 0) j0 += h;
-    int i1 = (i0 + 1) % w, j1 = (j0 + 1) % h;
-    uchar4 c00 = P.lut[j0 * w + i0], c10 = P.lut[j0 * w + i1], c01 = P.lut[j1 * w + i0], c11 = P.lut[j1 * w + i1];
-    float w00 = (1.0f - ax) * (1.0f - ay), w10 = ax * (1.0f - ay), w01 = (1.0f - ax) * ay, w11 = ax * ay;
-    const float k = 1.0f / 255.0f;
-    f3 r;
-    r.x = w00 * ((float)c00.x * k) + w10 * ((float)c10.x * k) + w01 * ((float)c01.x * k) + w11 * ((float)c11.x * k);
-    r.y = w00 * ((float)c00.y * k) + w10 * ((float)c10.y * k) + w01 * ((float)c01.y * k) + w11 * ((float)c11.y * k);
-    r.z = w00 * ((float)c00.z * k) + w10 * ((float)c10.z * k) + w01 * ((float)c01.z * k) + w11 * ((float)c11.z * k);
-    return r;
-}
-
-// ------------------------------------------------------------------ material textures (renderer.h:740-800) and equirect sky (renderer.h:802-851)
-// Build-defined sampling (the closest-hit / miss sources are missing): wrap, bilinear with CUDA's 1.8 fixed-point weights,
-// sRGB -> linear per texel before filtering for TexType::sRGB; sky (u, v) = (atan2(d.z, d.x) / 2pi + 0.5, acos(d.y) / pi).
-struct Bilin { int i0, i1, j0, j1; float w00, w10, w01, w11; };
-HD Bilin bilin(float u, float v, int w, int h)
-{
-    Bilin b;
-    float x = u * (float)w - 0.5f, y = v * (float)h - 0.5f;
-    float fx = floorf(x), fy = floorf(y);
-    float ax = floorf((x - fx) * 256.0f + 0.5f) * (1.0f / 256.0f);
-    float ay = floorf((y - fy) * 256.0f + 0.5f) * (1.0f / 256.0f);
-    b.i0 = (int)fx % w; if (b.i0 < 0) b.i0 += w;
-    b.j0 = (int)fy % h; if (b.j0 < 0) b.j0 += h;
-    b.i1 = (b.i0 + 1) % w; b.j1 = (b.j0 + 1) % h;
-    b.w00 = (1.0f - ax) * (1.0f - ay); b.w10 = ax * (1.0f - ay); b.w01 = (1.0f - ax) * ay; b.w11 = ax * ay;
-    return b;
-}
-HD f3 tex_fetch(const KParams& P, int slot, float u, float v)
-{
-    const uint4 d = P.tex_desc[slot];
-    const int w = (int)d.y, h = (int)d.z;
-    const Bilin b = bilin(u, v, w, h);
-    const uchar4* t = P.texels + d.x;
-    const uchar4 c00 = t[b.j0 * w + b.i0], c10 = t[b.j0 * w + b.i1], c01 = t[b.j1 * w + b.i0], c11 = t[b.j1 * w + b.i1];
-    f3 r;
-    if (d.w) {
-        const float* L = P.srgb_lut;
-        r.x = b.w00 * L[c00.x] + b.w10 * L[c10.x] + b.w01 * L[c01.x] + b.w11 * L[c11.x];
-        r.y = b.w00 * L[c00.y] + b.w10 * L[c10.y] + b.w01 * L[c01.y] + b.w11 * L[c11.y];
-        r.z = b.w00 * L[c00.z] + b.w10 * L[c10.z] + b.w01 * L[c01.z] + b.w11 * L[c11.z];
-    } else {
-        const float k = 1.0f / 255.0f;
-        r.x = b.w00 * ((float)c00.x * k) + b.w10 * ((float)c10.x * k) + b.w01 * ((float)c01.x * k) + b.w11 * ((float)c11.x * k);
-        r.y = b.w00 * ((float)c00.y * k) + b.w10 * ((float)c10.y * k) + b.w01 * ((float)c01.y * k) + b.w11 * ((float)c11.y * k);
-        r.z = b.w00 * ((float)c00.z * k) + b.w10 * ((float)c10.z * k) + b.w01 * ((float)c01.z * k) + b.w11 * ((float)c11.z * k);
-    }
-    return r;
-}
-HD f3 sky_fetch(const KParams& P, f3 d)
-{
-    const float u = p_atan2(d.z, d.x) * 0.15915494309189533577f + 0.5f;
-    const float v = p_acos(clampf(d.y, -1.0f, 1.0f)) * HJ_INV_PI;
-    const int w = P.sky_w, h = P.sky_h;
-    const Bilin b = bilin(u, v, w, h);
-    const float4 c00 = P.sky_tex[b.j0 * w + b.i0], c10 = P.sky_tex[b.j0 * w + b.i1], c01 = P.sky_tex[b.j1 * w + b.i0], c11 = P.sky_tex[b.j1 * w + b.i1];
-    return V(b.w00 * c00.x + b.w10 * c10.x + b.w01 * c01.x + b.w11 * c11.x,
-             b.w00 * c00.y + b.w10 * c10.y + b.w01 * c01.y + b.w11 * c11.y,
-             b.w00 * c00.z + b.w10 * c10.z + b.w01 * c01.z + b.w11 * c11.z);
-}
-
-// ------------------------------------------------------------------ DisneyBRDF (kernel/disneyBRDF.h:16-327)
-#define HJ_LOG_CLEARCOAT_ALPHA2 (-13.8155105579642741f) /* logf(0.001f*0.001f): the only argument clearcoat_D ever sees */
-#define HJ_CLEARCOAT_ALPHA 0.001f                          /* lerp(0.1f, 0.001f, 1.0f) with math.h:109-111 */
-
-struct Disney {
-    f3 basecolor;
-    float alpha, metallic, sheen, clearcoat;
-    bool is_thinfilm;
-};
-HD Disney disney_init(const Surface& s) // :165-177
-{
-    Disney d;
-    d.basecolor = s.basecolor;
-    d.alpha = clampf(s.roughness * s.roughness, 0.01f, 1.0f);
-    d.metallic = s.metallic;
-    d.sheen = s.sheen;
-    d.clearcoat = s.clearcoat;
-    d.is_thinfilm = s.is_thinfilm;
-    return d;
-}
-HD float ggx_D(float a, f3 wm) // :44-48 (same body in BSDFs.h:507-511)
-{
-    float term1 = wm.x * wm.x / (a * a) + wm.z * wm.z / (a * a) + wm.y * wm.y;
-    float term2 = HJ_PI * a * a * term1 * term1;
-    return 1.0f / term2;
-}
-HD float d_Lambda(float a, f3 w) // :58-61
-{
-    float delta = 1.0f + (a * a * w.x * w.x + a * a * w.z * w.z) / (w.y * w.y);
-    return (-1.0f + sqrtf(delta)) * 0.5f;
-}
-HD float d_G1(float a, f3 w) { return 1.0f / (1.0f + d_Lambda(a, w)); }                             // :50-52
-HD float d_G2(float a, f3 wi, f3 wo) { return 1.0f / (1.0f + d_Lambda(a, wi) + d_Lambda(a, wo)); }   // :54-56
-HD float d_getPDFDiffuse(f3 wi) { return fabsf(wi.y) * HJ_INV_PI; }                                  // :40-42
-HD f3 d_sampleDiffuse(f2 uv, float& pdf) // :30-38
-{
-    float theta = 0.5f * p_acos(1.0f - 2.0f * uv.x);
-    float phi = 2.0f * HJ_PI * uv.y;
-    float sinTheta, cosTheta, sp, cp;
-    p_sincos(theta, sinTheta, cosTheta);
-    p_sincos(phi, sp, cp);
-    f3 wi = V(cp * sinTheta, cosTheta, sp * sinTheta);
-    pdf = d_getPDFDiffuse(wi);
-    return wi;
-}
-// spherical-cap VNDF sampling (arXiv 2306.05044): disneyBRDF.h:64-80 == BSDFs.h:616-632
-HD f3 sample_visible_normal(float alpha, f2 uv, f3 wo)
-{
-    f3 strech_wo = normalize(V(wo.x * alpha, wo.y, wo.z * alpha));
-    float phi = 2.0f * HJ_PI * uv.x;
-    float z = fmaf((1.0f - uv.y), (1.0f + strech_wo.y), -strech_wo.y);
-    float sinTheta = sqrtf(clampf(1.0f - z * z, 0.0f, 1.0f));
-    float sp, cp;
-    p_sincos(phi, sp, cp);
-    float x = cp * sinTheta;
-    float y = sp * sinTheta;
-    f3 c = V(x, z, y);
-    f3 h = c + strech_wo;
-    return normalize(V(h.x * alpha, h.y, h.z * alpha));
-}
-HD float d_getPDFSpecular(float a, f3 wm, f3 wo) // :88-90
-{
-    return 0.25f * ggx_D(a, wm) * d_G1(a, wo) * absdot(wo, wm) / (absdot(wm, wo) * fabsf(wo.y));
-}
-HD float clearcoat_D(f3 wm, float alpha) // :131-139
-{
-    float alpha2 = alpha * alpha;
-    float t = 1.0f + (alpha2 - 1.0f) * wm.y * wm.y;
-    return (alpha2 - 1.0f) / (HJ_PI * HJ_LOG_CLEARCOAT_ALPHA2 * t);
-}
-HD float d_getPDFClearcoat(f3 wm, f3 wo) // :102-104
-{
-    return clearcoat_D(wm, HJ_CLEARCOAT_ALPHA) * fabsf(wm.y) / (4.0f * fabsf(dot(wm, wo)));
-}
-HD f3 d_sampleClearcoat(f2 uv, f3 wo, float& pdf) // :93-100
-{
-    const float ca = HJ_CLEARCOAT_ALPHA;
-    float cosineTheta = sqrtf(fmaxf((1.0f - p_pow(ca * ca, 1.0f - uv.x)) / (1.0f - ca * ca), 0.0f));
-    float sinTheta = sqrtf(fmaxf(1.0f - cosineTheta * cosineTheta, 0.0f));
-    float phi = HJ_PI2 * uv.y;
-    float sp, cp;
-    p_sincos(phi, sp, cp);
-    f3 wm = V(cp * sinTheta, cosineTheta, sp * sinTheta);
-    pdf = d_getPDFClearcoat(wm, wo);
-    return wm;
-}
-HD float f_tSchlick(float wn, float F90) // :106-109
-{
-    float delta = fmaxf(1.0f - wn, 0.0f);
-    return 1.0f + (F90 - 1.0f) * delta * delta * delta * delta * delta;
-}
-HD float clearcoat_Lambda(f3 w, float alpha) // :126-129
-{
-    float term1 = 1.0f + (alpha * alpha * w.x * w.x + alpha * alpha * w.z * w.z) / (w.y * w.y);
-    return 0.5f * (-1.0f + sqrtf(term1));
-}
-HD f3 disney_eval(const KParams& P, const Disney& d, f3 wo, f3 wi) // :179-235
-{
-    f3 wm = normalize(wo + wi);
-    float dot_wi_n = fabsf(wi.y);
-    float dot_wo_n = fabsf(wi.y); // sic (:189)
-    float cosine_d = absdot(wi, wm);
-    float F_D90 = 0.5f + 2.0f * d.alpha * cosine_d * cosine_d;
-    float f_tsi = f_tSchlick(dot_wi_n, F_D90);
-    float f_tso = f_tSchlick(dot_wo_n, F_D90);
-    f3 f_diffuse = d.basecolor * f_tsi * f_tso * HJ_INV_PI;
-    float deltacos = 1.0f / (dot_wi_n + dot_wo_n) - 0.5f;
-    f3 f_subsurface = d.basecolor * HJ_INV_PI * 1.25f * (f_tsi * f_tso * deltacos + 0.5f);
-    f3 F0 = lerp3(V1(0.08f), d.basecolor, d.metallic);
-    if (d.is_thinfilm) { // :213-217
-        float thickness = d.basecolor.x;
-        float cosine = absdot(wi, wm);
-        F0 = lut_fetch(P, thickness, cosine);
-    }
-    // specular(), :112-120
-    f3 f_specular;
-    {
-        float ggxD = ggx_D(d.alpha, wm);
-        float ggxG = d_G2(d.alpha, wi, wo);
-        f3 ggxF = schlick3(F0, wo, wm);
-        f_specular = (ggxF * 0.25f * ggxD * ggxG) / (fabsf(wo.y) * fabsf(wi.y));
-    }
-    float delta = fmaxf(1.0f - absdot(wi, wm), 0.0f);
-    f3 f_sheen = V1(1.0f) * d.sheen * delta * delta * delta * delta * delta;
-    // clearcoat(), :142-150
-    f3 f_clearcoat;
-    {
-        float cD = clearcoat_D(wm, HJ_CLEARCOAT_ALPHA);
-        float cG = 1.0f / (1.0f + clearcoat_Lambda(wi, 0.25f) + clearcoat_Lambda(wo, 0.25f));
-        f3 cF = schlick3(V1(0.04f), wo, wm);
-        f_clearcoat = ((cF * (0.25f * cD * cG)) / (fabsf(wo.y) * fabsf(wi.y))) * 0.25f;
-    }
-    // m_subsurface is forced to 0 (:170): lerp(f_diffuse, f_subsurface, 0) = f_diffuse + (f_subsurface - f_diffuse) * 0
-    return (lerp3(f_diffuse, f_subsurface, 0.0f) + f_sheen) * (1.0f - d.metallic) + f_specular + f_clearcoat * d.clearcoat;
-}
-HD f3 disney_sample(const KParams& P, const Disney& d, f3 wo, f3& wi, float& pdf, CMJState& st) // :237-307
-{
-    float diffuseWeight = 1.0f * (1.0f - d.metallic);
-    float specularWeight = 0.5f;
-    float clearcoatWeight = 0.0f;
-    float sumWeight = diffuseWeight + specularWeight + clearcoatWeight;
-    float dw = diffuseWeight / sumWeight;
-    float sw = specularWeight / sumWeight;
-    float cw = clearcoatWeight / sumWeight;
-    float select_p = cmj_1d(st);
-    float pdf_diffuse = 1.0f, pdf_specular = 1.0f, pdf_clearcoat = 1.0f;
-    f2 xi = cmj_2d(st);
-    if (select_p < dw) {
-        wi = d_sampleDiffuse(xi, pdf_diffuse);
-        f3 wm = normalize(wi + wo);
-        pdf_specular = d_getPDFSpecular(d.alpha, wm, wo);
-        pdf_clearcoat = d_getPDFClearcoat(wm, wo);
-    } else if (select_p < dw + sw) {
-        f3 wm = sample_visible_normal(d.alpha, xi, wo);
-        pdf_specular = d_getPDFSpecular(d.alpha, wm, wo);
-        wi = reflect3(-wo, wm);
-        pdf_diffuse = d_getPDFDiffuse(wi);
-        pdf_clearcoat = d_getPDFClearcoat(wm, wo);
-    } else {
-        f3 wm = d_sampleClearcoat(xi, wo, pdf_clearcoat);
-        wi = reflect3(-wo, wm);
-        pdf_diffuse = d_getPDFDiffuse(wi);
-        pdf_specular = d_getPDFSpecular(d.alpha, wm, wo);
-    }
-    pdf = dw * pdf_diffuse + sw * pdf_specular + cw * pdf_clearcoat;
-    if (wi.y < 0.0f) { pdf = 1.0f; return V1(0.0f); }
-    return disney_eval(P, d, wo, wi);
-}
-HD float disney_pdf(const Disney& d, f3 wo, f3 wi) // :309-326
-{
-    float diffuseWeight = 1.0f * (1.0f - d.metallic);
-    float specularWeight = 0.5f, clearcoatWeight = 0.0f;
-    float sumWeight = diffuseWeight + specularWeight + clearcoatWeight;
-    float dw = diffuseWeight / sumWeight, sw = specularWeight / sumWeight;
-    f3 wm = normalize(wo + wi);
-    return dw * d_getPDFDiffuse(wi) + sw * d_getPDFSpecular(d.alpha, wm, wo);
-}
-
-// ------------------------------------------------------------------ MetaMaterialGlass (kernel/BSDFs.h:404-479): negative refractive index
-HD f3 metaglass_sample(float ior, f3 wo, f3& wi, float& pdf, CMJState& st)
-{
-    const f3 rho = V1(1.0f); // BSDFs.h:998
-    float ior_o = 1.0f, ior_i = ior, sign = 1.0f;
-    f3 lwo = wo, lwi;
-    f3 n = V(0, 1, 0);
-    if (wo.y < 0.0f) { ior_o = ior; ior_i = 1.0f; lwo.y = -lwo.y; sign = -1.0f; }
-    const float fr = schlick_ior(ior_o, ior_i, lwo, n);
-    float p = cmj_1d(st);
-    f3 t;
-    if (p < fr) lwi = reflect3(-lwo, n);
-    else if (refract3(lwo, n, ior_o, ior_i, t)) lwi = reflect3(-t, V(0, -1, 0)); // tangential flip (:454)
-    else lwi = reflect3(-lwo, n);
-    pdf = 1;
-    f3 evalbsdf = rho / fabsf(lwi.y);
-    wi = lwi;
-    wi.y = sign * wi.y;
-    return evalbsdf;
-}
-
-// ------------------------------------------------------------------ EnagyConservationGGX (kernel/BSDFs.h:483-852): Heitz multiple-scattering walk
-HD float ms_C1(float h) { return fminf(1.0f, fmaxf(0.0f, 0.5f * (h + 1.0f))); }        // :494-500
-HD float ms_invC1(float U) { return fmaxf(-1.0f, fminf(1.0f, 2.0f * U - 1.0f)); }      // :502-505
-HD float ms_Lambda(float a, f3 v) // :525-532 (the -1.0 / 2.0f literals make this a double expression)
-{
-    if (v.y > 0.9999f) return 0.0f;
-    if (v.y < -0.9999f) return -1.0f;
-    float delta = 1.0f + (a * a * v.x * v.x + a * a * v.z * v.z) / (v.y * v.y);
-    float sg = (v.y > 0.0f) ? 1.0f : -1.0f;
-    return (float)((-1.0 + (double)(sg * sqrtf(delta))) / (double)2.0f);
-}
-HD float ms_G1_Height(float a, f3 wi, float h0) // :551-563
-{
-    if (wi.y > 0.9999f) return 1.0f;
-    if (wi.y <= 0.0f) return 0.0f;
-    const float C1_h0 = ms_C1(h0);
-    const float Lambda = ms_Lambda(a, wi);
-    return p_pow(C1_h0, Lambda);
-}
-HD float ms_sampleHeight(float a, f3 wr, float hr, float U) // :566-586
-{
-    if (wr.y > 0.9999f) return HJ_FLT_MAX;
-    if (wr.y < -0.9999f) return ms_invC1(U * ms_C1(hr));
-    if (fabsf(wr.y) < 0.0001f) return hr;
-    const float G_1_ = ms_G1_Height(a, wr, hr);
-    if (U > 1.0f - G_1_) return HJ_FLT_MAX;
-    return ms_invC1(ms_C1(hr) / p_pow((1.0f - U), 1.0f / ms_Lambda(a, wr)));
-}
-HD f3 msggx_sampleBSDF(f3 F0, float alpha, f3 wo_in, f3& wi_out, CMJState& st, float& pdf) // :784-819 + :843-851
-{
-    f3 wr = -wo_in;
-    float hr = 1.0f + ms_invC1(0.999f);
-    int order = 0;
-    f3 weight = V1(1.0f);
-    bool early = false;
-    f3 early_ret = V1(0.0f);
-    for (;;) {
-        float U = cmj_1d(st);
-        hr = ms_sampleHeight(alpha, wr, hr, U);
-        if (hr == HJ_FLT_MAX) break;
-        else order++;
-        if (order > 5) { wi_out = V(0, 0, 1); early = true; early_ret = V(0, 0, 0); break; }
-        // samplePhaseFunction(-wr, state, weight_1), :737-746
-        f3 wi = -wr;
-        const f2 uv = cmj_2d(st);
-        f3 wm = sample_visible_normal(alpha, uv, wi);
-        wr = (-wi) + (wm * 2.0f) * dot(wi, wm);
-        f3 weight_1 = schlick3(F0, wi, wm);
-        weight = weight * weight_1;
-        if ((hr != hr) || (wr.z != wr.z)) { early = true; early_ret = V(0, 0, 1); break; } // wi_out untouched (:813-814)
-    }
-    f3 bsdf;
-    if (early) bsdf = early_ret;
-    else { wi_out = wr; bsdf = weight; }
-    if (wi_out.y < 0.0f || order > 5) return V1(0.0f); // pdf stays as the caller initialised it (:846-848)
-    pdf = fabsf(wi_out.y);
-    return bsdf;
-}
-
-// ------------------------------------------------------------------ BSDF dispatch (kernel/BSDFs.h:979-1038)
-HD f3 bsdf_eval(const KParams& P, const Surface& s, f3 wo, f3 wi)
-{
-    if (s.is_specular) return V1(0.0f);
-    Disney d = disney_init(s);
-    return disney_eval(P, d, wo, wi);
-}
-HD f3 bsdf_sample(const KParams& P, const Surface& s, f3 wo, f3& wi, float& pdf, CMJState& st)
-{
-    if (s.is_specular) return metaglass_sample(s.ior, wo, wi, pdf, st);
-    if (!(s.metallic > 0.5f)) {
-        Disney d = disney_init(s);
-        return disney_sample(P, d, wo, wi, pdf, st);
-    }
-    return msggx_sampleBSDF(s.basecolor, clampf(s.roughness * s.roughness, 0.0001f, 1.0f), wo, wi, st, pdf);
-}
-HD float bsdf_pdf(const Surface& s, f3 wo, f3 wi)
-{
-    if (s.is_specular) return 0.0f;
-    Disney d = disney_init(s);
-    return disney_pdf(d, wo, wi);
-}
-
-// ------------------------------------------------------------------ traversal: replaces optixTrace (kernel/rt.h:15-69) + RT cores
-struct Counters {
-    uint32_t box, tri;
-#ifdef HJR_TIMING
-    unsigned long long t_node, t_leaf;
-#endif
-};
-
-HD float dotf(f3 a, f3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
-HD f3 crossf(f3 a, f3 b)
-{
-    return V(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
-}
-// canonical ray/triangle test — the same operation sequence as the oracle's ray_tri()
-HD bool ray_tri(f3 v0, f3 v1, f3 v2, f3 o, f3 d, float tmin, float tmax, float& t, float& b1, float& b2)
-{
-    f3 e1 = v1 - v0, e2 = v2 - v0;
-    f3 p = crossf(d, e2);
-    float det = dotf(e1, p);
-    if (det == 0.0f) return false;
-    float inv = 1.0f / det;
-    f3 tv = o - v0;
-    float u = dotf(tv, p) * inv;
-    if (!(u >= 0.0f && u <= 1.0f)) return false;
-    f3 q = crossf(tv, e1);
-    float v = dotf(d, q) * inv;
-    if (!(v >= 0.0f && u + v <= 1.0f)) return false;
-    float tt = dotf(e2, q) * inv;
-    if (!(tt > tmin && tt < tmax)) return false;
-    t = tt; b1 = u; b2 = v;
-    return true;
-}
-
-// ---- per-lane traversal stack in LDS, element i of this lane at stack[i * BLOCK] (conflict-free columns).  Small scenes that
-// are staged into LDS use 16-bit entries (node index < 32768, or leaf: bit15 | count << 13 | first triangle < 8192), which
-// halves the stack's LDS footprint; everything else uses the 32-bit child refs as they are.
-template <typename ST> HD ST stack_enc(uint32_t ref);
-template <> HD uint32_t stack_enc<uint32_t>(uint32_t ref) { return ref; }
-template <> HD uint16_t stack_enc<uint16_t>(uint32_t ref)
-{
-    return (uint16_t)((ref & HJR_LEAF_FLAG) ? (0x8000u | (((ref >> 27) & 3u) << 13) | (ref & 0x1fffu)) : ref);
-}
-HD uint32_t stack_dec(uint32_t r) { return r; }
-HD uint32_t stack_dec(uint16_t r16)
-{
-    const uint32_t r = r16;
-    return (r & 0x8000u) ? (HJR_LEAF_FLAG | (((r >> 13) & 3u) << 27) | (r & 0x1fffu)) : r;
-}
-
-// One lane's traversal stack.  SHORT == 0: every entry in LDS (column of this lane).  SHORT > 0 (kernels that read the BVH from
-// memory): only the top-of-tree SHORT entries are in LDS, deeper ones overflow into a per-lane column of a global buffer
-// ([level][lane], coalesced when neighbouring lanes overflow together).  The exact worst-case depth of a BVH4 over a million
-// triangles is ~46 entries, traversal rarely needs more than a dozen: with the whole stack in LDS the stacks, not the
-// registers, capped the occupancy at 3 workgroups per CU.
-#ifndef HJR_SHORT_STACK
-#define HJR_SHORT_STACK 16
-#endif
-template <typename E, int BLOCK_, int SHORT>
-struct LaneStack {
-    E* lds;
-    uint32_t* spill;
-    uint32_t spill_stride;
-    HD void put(int i, uint32_t ref)
-    {
-        if (SHORT == 0 || i < SHORT) lds[i * BLOCK_] = stack_enc<E>(ref);
-        else spill[(size_t)(i - SHORT) * spill_stride] = ref;
-    }
-    HD uint32_t get(int i) const
-    {
-        if (SHORT == 0 || i < SHORT) return stack_dec(lds[i * BLOCK_]);
-        return spill[(size_t)(i - SHORT) * spill_stride];
-    }
-};
-
-// ---- box-test side of a ray.  The slab test only has to be conservative (boxes are padded): it uses the
-// 1-ulp hardware reciprocal and (plane - o) * inv evaluated as fma(plane, inv, -o * inv).  Direction components smaller than
-// 1e-30 are clamped (sign kept) so that inv stays finite and no inf - inf can appear for axis-parallel rays.
-struct BoxRay {
-    f3 inv, oi;
-    uint32_t sx, sy, sz; // BVH4 only: 1 when the direction component is negative (near plane row = hi)
-};
-HD float box_dir(float d) { return (fabsf(d) < 1e-30f) ? copysignf(1e-30f, d) : d; }
-HD BoxRay box_ray(f3 o, f3 d)
-{
-    BoxRay r;
-    const f3 dd = V(box_dir(d.x), box_dir(d.y), box_dir(d.z));
-    r.inv = V(__builtin_amdgcn_rcpf(dd.x), __builtin_amdgcn_rcpf(dd.y), __builtin_amdgcn_rcpf(dd.z));
-    r.oi = V(-o.x * r.inv.x, -o.y * r.inv.y, -o.z * r.inv.z);
-    r.sx = dd.x < 0.0f ? 1u : 0u; r.sy = dd.y < 0.0f ? 1u : 0u; r.sz = dd.z < 0.0f ? 1u : 0u; // dead code in the BVH2 kernels
-    return r;
-}
-
-#define HJR_TRAV_DONE 0xffffffffu
-// One inner-node step: tests the children of node `cur` against [tmin, tfar], continues with the nearest hit child, pushes
-// the other hit children, or pops (HJR_TRAV_DONE when the stack is empty).  Returns the number of boxes tested.
-template <int WIDTH, int BLOCK, typename ST>
-HD uint32_t node_step(const float4* nodes, uint32_t& cur, const BoxRay& R, float tmin, float tfar, ST& stack, int& sp)
-{
-    if constexpr (WIDTH == 2) {
-    const float4* nd = nodes + cur * HJR_NODE2_F4;
-    const float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
-    const f3 inv = R.inv, oi = R.oi;
-    float t0 = fmaf(q0.x, inv.x, oi.x), t1 = fmaf(q0.w, inv.x, oi.x);
-    float lo0 = fminf(t0, t1), hi0 = fmaxf(t0, t1);
-    t0 = fmaf(q0.y, inv.y, oi.y); t1 = fmaf(q1.x, inv.y, oi.y);
-    lo0 = fmaxf(lo0, fminf(t0, t1)); hi0 = fminf(hi0, fmaxf(t0, t1));
-    t0 = fmaf(q0.z, inv.z, oi.z); t1 = fmaf(q1.y, inv.z, oi.z);
-    lo0 = fmaxf(lo0, fminf(t0, t1)); hi0 = fminf(hi0, fmaxf(t0, t1));
-    lo0 = fmaxf(lo0, tmin); hi0 = fminf(hi0, tfar);
-    t0 = fmaf(q1.z, inv.x, oi.x); t1 = fmaf(q2.y, inv.x, oi.x);
-    float lo1 = fminf(t0, t1), hi1 = fmaxf(t0, t1);
-    t0 = fmaf(q1.w, inv.y, oi.y); t1 = fmaf(q2.z, inv.y, oi.y);
-    lo1 = fmaxf(lo1, fminf(t0, t1)); hi1 = fminf(hi1, fmaxf(t0, t1));
-    t0 = fmaf(q2.x, inv.z, oi.z); t1 = fmaf(q2.w, inv.z, oi.z);
-    lo1 = fmaxf(lo1, fminf(t0, t1)); hi1 = fminf(hi1, fmaxf(t0, t1));
-    lo1 = fmaxf(lo1, tmin); hi1 = fminf(hi1, tfar);
-    const bool h0 = lo0 <= hi0, h1 = lo1 <= hi1; // conservative through the 2^-15 box padding (>= 16x the rounding error of t)
-    const uint32_t c0 = f2bits(q3.x), c1 = f2bits(q3.y);
-    if (h0 && h1) {
-        const bool swap = lo1 < lo0;
-        stack.put(sp, swap ? c0 : c1);
-        sp++;
-        cur = swap ? c1 : c0;
-    } else if (h0) cur = c0;
-    else if (h1) cur = c1;
-    else if (sp > 0) { sp--; cur = stack.get(sp); }
-    else cur = HJR_TRAV_DONE;
-    return 2u;
-    } else {
-    const float4* nd = nodes + cur * HJR_NODE4_F4;
-    const f3 inv = R.inv, oi = R.oi;
-    const float INF = bits2f(0x7f800000u);
-    // near / far plane rows picked by the ray's direction signs: no min/max per axis
-    const float4 nx = nd[0 + R.sx], fx = nd[1 - R.sx];
-    const float4 ny = nd[2 + R.sy], fy = nd[3 - R.sy];
-    const float4 nz = nd[4 + R.sz], fz = nd[5 - R.sz];
-    const float4 rr = nd[6];
-#define HJR_CHILD(c, C)                                                                                                  \
-    float tn##C = fmaxf(fmaxf(fmaf(nx.c, inv.x, oi.x), fmaf(ny.c, inv.y, oi.y)), fmaxf(fmaf(nz.c, inv.z, oi.z), tmin)); \
-    const float tf##C = fminf(fminf(fmaf(fx.c, inv.x, oi.x), fmaf(fy.c, inv.y, oi.y)), fminf(fmaf(fz.c, inv.z, oi.z), tfar)); \
-    const bool h##C = tn##C <= tf##C;                                                                                   \
-    tn##C = h##C ? tn##C : INF;
-    HJR_CHILD(x, 0) HJR_CHILD(y, 1) HJR_CHILD(z, 2) HJR_CHILD(w, 3)
-#undef HJR_CHILD
-    const uint32_t r0 = f2bits(rr.x), r1 = f2bits(rr.y), r2 = f2bits(rr.z), r3 = f2bits(rr.w);
-    const float m = fminf(fminf(tn0, tn1), fminf(tn2, tn3));
-    // nearest hit child first (ties: lowest slot); the other hit children are pushed in slot order
-    const int sel = (tn0 == m) ? 0 : ((tn1 == m) ? 1 : ((tn2 == m) ? 2 : 3));
-    if (h3 && sel != 3) { stack.put(sp, r3); sp++; }
-    if (h2 && sel != 2) { stack.put(sp, r2); sp++; }
-    if (h1 && sel != 1) { stack.put(sp, r1); sp++; }
-    if (h0 && sel != 0) { stack.put(sp, r0); sp++; }
-    if (h0 || h1 || h2 || h3) cur = (sel == 0) ? r0 : ((sel == 1) ? r1 : ((sel == 2) ? r2 : r3));
-    else if (sp > 0) { sp--; cur = stack.get(sp); }
-    else cur = HJR_TRAV_DONE;
-    return 4u;
-    }
-}
-
-struct Hit { float t, b1, b2; uint32_t k, prim; };
-
-// stack: this lane's column of the LDS stack, element i at stack[i * BLOCK]
-template <bool ANY, bool STATS, int WIDTH, int BLOCK, typename ST>
-HD bool traverse(const float4* nodes, const float4* tris, f3 o, f3 d, float tmin, float tmax, Hit& hit, ST& stack, Counters& cnt)
-{
-    const BoxRay R = box_ray(o, d);
-    int sp = 0;
-    uint32_t cur = 0;
-    hit.prim = 0xffffffffu;
-    hit.t = tmax;
-    for (;;) {
-        while (!(cur & HJR_LEAF_FLAG)) { // descend through inner nodes until this lane holds a leaf (or is done)
-            const uint32_t nb = node_step<WIDTH, BLOCK, ST>(nodes, cur, R, tmin, hit.t, stack, sp);
-            if (STATS) cnt.box += nb;
-        }
-        if (cur == HJR_TRAV_DONE) break;
-        const uint32_t first = cur & 0x07ffffffu, count = (cur >> 27) & 15u;
-        for (uint32_t i = 0; i < count; i++) {
-            const float4* g = tris + (first + i) * HJR_TRI_F4;
-            const float4 g0 = g[0], g1 = g[1], g2 = g[2];
-            float t, b1, b2;
-            if (STATS) cnt.tri++;
-            if (ray_tri(V(g0.x, g0.y, g0.z), V(g0.w, g1.x, g1.y), V(g1.z, g1.w, g2.x), o, d, tmin, tmax, t, b1, b2)) {
-                if (ANY) return true;
-                const uint32_t prim = f2bits(g2.y);
-                // order-independent closest-hit rule: smaller t wins; equal t -> smaller global prim id
-                if (hit.prim == 0xffffffffu || t < hit.t || (t == hit.t && prim < hit.prim)) {
-                    hit.t = t; hit.b1 = b1; hit.b2 = b2; hit.k = first + i; hit.prim = prim;
-                }
-            }
-        }
-        if (sp == 0) break;
-        sp--;
-        cur = stack.get(sp);
-    }
-    return hit.prim != 0xffffffffu;
-}
-
-// Fused traversal of two rays per lane in ONE loop: ray A = the pending NEE shadow ray of the bounce just shaded (any-hit),
-// ray B = the next closest-hit ray (continuation or a regenerated primary ray).  A lane moves on to B the moment its A is
-// resolved, without waiting for the rest of the wave, so the wave's trip count is max_lanes(tripsA + tripsB) instead of
-// max(tripsA) + max(tripsB) — the SIMT cost of per-lane trip-count variance drops by ~1/3 (profiles/r01_experiments.md).
-// Results are identical to two separate traversals.
-//
-// Straggler carry-over (CARRY > 0): the loop also ends when at most CARRY lanes are still traversing (and at least one
-// lane of this round has finished).  Those lanes keep their traversal state (TravCarry + hit + their LDS stack column),
-// skip the shading that follows and resume in the next round next to the other lanes' new rays: the wave's trip count per
-// round is set by the (64 - CARRY)-th slowest lane instead of the slowest one.  Per-lane results do not change.  The
-// threshold trades traversal lane-occupancy against shading lane-occupancy (profiles/r01_experiments.md): 8 for the
-// LDS-resident scenes (shading-heavy), 32 when nodes come from memory (traversal-heavy).
-#ifndef HJR_CARRY_LDS
-#define HJR_CARRY_LDS 8
-#endif
-#ifndef HJR_CARRY_MEM
-#define HJR_CARRY_MEM 32
-#endif
-struct TravCarry { uint32_t cur; int sp, phase; };
-template <bool STATS, int WIDTH, int BLOCK, typename ST, int CARRY>
-HD bool traverse_fused(const float4* nodes, const float4* tris, const bool a_valid, const f3 ao, const f3 ad, const float a_tmax, const bool b_valid,
-                       const f3 bo, const f3 bd, bool& occluded, Hit& hit, ST& stack, Counters& ca, Counters& cb, const bool resume, TravCarry& tc)
-{
-    const float tmin = 0.001f;
-    int phase, sp;
-    uint32_t cur;
-    if (CARRY > 0 && resume) { phase = tc.phase; sp = tc.sp; cur = tc.cur; } // occluded / hit are the caller's, kept across rounds
-    else {
-        occluded = false;
-        hit.prim = 0xffffffffu;
-        hit.t = 1e16f;
-        phase = a_valid ? 0 : (b_valid ? 1 : 2);
-        sp = 0;
-        cur = (phase < 2) ? 0u : HJR_TRAV_DONE;
-    }
-    f3 o = (phase == 0) ? ao : bo;
-    f3 d = (phase == 0) ? ad : bd;
-    BoxRay R = box_ray(o, d);
-    const int n_start = CARRY > 0 ? __popcll(__ballot(phase < 2)) : 0;
-#ifdef HJR_TIMING
-    unsigned long long t_node = 0, t_leaf = 0, t_last = __builtin_amdgcn_s_memtime();
-#endif
-    for (;;) {
-        if (CARRY > 0) {
-            const int n_act = __popcll(__ballot(phase < 2));
-            if (n_act == 0 || (n_act <= CARRY && n_act < n_start)) break;
-        } else if (__ballot(phase < 2) == 0ull) break;
-        if (phase < 2) {
-        // "while-while" traversal: every lane first descends through inner nodes until it holds a leaf (or is out of work) ...
-        while (!(cur & HJR_LEAF_FLAG)) {
-            const float tfar = (phase == 0) ? a_tmax : hit.t;
-            const uint32_t nb = node_step<WIDTH, BLOCK, ST>(nodes, cur, R, tmin, tfar, stack, sp);
-            if (STATS) { if (phase == 0) ca.box += nb; else cb.box += nb; }
-        }
-#ifdef HJR_TIMING
-        { __builtin_amdgcn_sched_barrier(0); unsigned long long now_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); t_node += now_ - t_last; t_last = now_; }
-#endif
-        // ... then all lanes test their leaf's triangles together
-        bool done = (cur == HJR_TRAV_DONE);
-        if (!done) {
-            const uint32_t first = cur & 0x07ffffffu, count = (cur >> 27) & 15u;
-            const float tri_tmax = (phase == 0) ? a_tmax : 1e16f;
-            for (uint32_t i = 0; i < count; i++) {
-                const float4* g = tris + (first + i) * HJR_TRI_F4;
-                const float4 g0 = g[0], g1 = g[1], g2 = g[2];
-                float t, b1, b2;
-                if (STATS) { if (phase == 0) ca.tri++; else cb.tri++; }
-                if (ray_tri(V(g0.x, g0.y, g0.z), V(g0.w, g1.x, g1.y), V(g1.z, g1.w, g2.x), o, d, tmin, tri_tmax, t, b1, b2)) {
-                    if (phase == 0) { occluded = true; done = true; break; }
-                    const uint32_t prim = f2bits(g2.y);
-                    // order-independent closest-hit rule: smaller t wins; equal t -> smaller global prim id
-                    if (hit.prim == 0xffffffffu || t < hit.t || (t == hit.t && prim < hit.prim)) {
-                        hit.t = t; hit.b1 = b1; hit.b2 = b2; hit.k = first + i; hit.prim = prim;
-                    }
-                }
-            }
-            if (!done) {
-                if (sp > 0) { sp--; cur = stack.get(sp); }
-                else done = true;
-            }
-        }
-        if (done) {
-            if (phase == 0 && b_valid) { // this lane's shadow ray is resolved: start its closest-hit ray right away
-                phase = 1;
-                o = bo; d = bd;
-                R = box_ray(o, d);
-                sp = 0; cur = 0;
-            } else { phase = 2; cur = HJR_TRAV_DONE; }
-        }
-#ifdef HJR_TIMING
-        { __builtin_amdgcn_sched_barrier(0); unsigned long long now_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); t_leaf += now_ - t_last; t_last = now_; }
-#endif
-    } }
-#ifdef HJR_TIMING
-    ca.t_node = t_node; ca.t_leaf = t_leaf;
-#endif
-    if (CARRY > 0) { tc.phase = phase; tc.sp = sp; tc.cur = cur; return phase < 2; }
-    return false;
-}
+#include "hjr_params.hip.h"
+#include "hjr_sampling.hip.h"
+#include "hjr_bsdf.hip.h"
+#include "hjr_traverse.hip.h"
 
 // ------------------------------------------------------------------ closest-hit / miss programs (build-defined)
 struct HitInfo { // the Payload fields the integrators read (kernel/Payload.h:12-42)

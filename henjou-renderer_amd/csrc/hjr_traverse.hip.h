@@ -1,0 +1,302 @@
+// Software ray traversal (replaces optixTrace + the RT cores): canonical ray / triangle test, per-lane stacks, BVH2 / BVH4 node
+// steps, stand-alone traversal and the fused two-ray traversal with straggler carry-over.
+#pragma once
+#include "hjr_params.hip.h"
+
+// ------------------------------------------------------------------ traversal: replaces optixTrace (kernel/rt.h:15-69) + RT cores
+struct Counters {
+    uint32_t box, tri;
+#ifdef HJR_TIMING
+    unsigned long long t_node, t_leaf;
+#endif
+};
+
+HD float dotf(f3 a, f3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+HD f3 crossf(f3 a, f3 b)
+{
+    return V(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
+}
+// canonical ray/triangle test — the same operation sequence as the oracle's ray_tri()
+HD bool ray_tri(f3 v0, f3 v1, f3 v2, f3 o, f3 d, float tmin, float tmax, float& t, float& b1, float& b2)
+{
+    f3 e1 = v1 - v0, e2 = v2 - v0;
+    f3 p = crossf(d, e2);
+    float det = dotf(e1, p);
+    if (det == 0.0f) return false;
+    float inv = 1.0f / det;
+    f3 tv = o - v0;
+    float u = dotf(tv, p) * inv;
+    if (!(u >= 0.0f && u <= 1.0f)) return false;
+    f3 q = crossf(tv, e1);
+    float v = dotf(d, q) * inv;
+    if (!(v >= 0.0f && u + v <= 1.0f)) return false;
+    float tt = dotf(e2, q) * inv;
+    if (!(tt > tmin && tt < tmax)) return false;
+    t = tt; b1 = u; b2 = v;
+    return true;
+}
+
+// ---- per-lane traversal stack in LDS, element i of this lane at stack[i * BLOCK] (conflict-free columns).  Small scenes that
+// are staged into LDS use 16-bit entries (node index < 32768, or leaf: bit15 | count << 13 | first triangle < 8192), which
+// halves the stack's LDS footprint; everything else uses the 32-bit child refs as they are.
+template <typename ST> HD ST stack_enc(uint32_t ref);
+template <> HD uint32_t stack_enc<uint32_t>(uint32_t ref) { return ref; }
+template <> HD uint16_t stack_enc<uint16_t>(uint32_t ref)
+{
+    return (uint16_t)((ref & HJR_LEAF_FLAG) ? (0x8000u | (((ref >> 27) & 3u) << 13) | (ref & 0x1fffu)) : ref);
+}
+HD uint32_t stack_dec(uint32_t r) { return r; }
+HD uint32_t stack_dec(uint16_t r16)
+{
+    const uint32_t r = r16;
+    return (r & 0x8000u) ? (HJR_LEAF_FLAG | (((r >> 13) & 3u) << 27) | (r & 0x1fffu)) : r;
+}
+
+// One lane's traversal stack.  SHORT == 0: every entry in LDS (column of this lane).  SHORT > 0 (kernels that read the BVH from
+// memory): only the top-of-tree SHORT entries are in LDS, deeper ones overflow into a per-lane column of a global buffer
+// ([level][lane], coalesced when neighbouring lanes overflow together).  The exact worst-case depth of a BVH4 over a million
+// triangles is ~46 entries, traversal rarely needs more than a dozen: with the whole stack in LDS the stacks, not the
+// registers, capped the occupancy at 3 workgroups per CU.
+#ifndef HJR_SHORT_STACK
+#define HJR_SHORT_STACK 16
+#endif
+template <typename E, int BLOCK_, int SHORT>
+struct LaneStack {
+    E* lds;
+    uint32_t* spill;
+    uint32_t spill_stride;
+    HD void put(int i, uint32_t ref)
+    {
+        if (SHORT == 0 || i < SHORT) lds[i * BLOCK_] = stack_enc<E>(ref);
+        else spill[(size_t)(i - SHORT) * spill_stride] = ref;
+    }
+    HD uint32_t get(int i) const
+    {
+        if (SHORT == 0 || i < SHORT) return stack_dec(lds[i * BLOCK_]);
+        return spill[(size_t)(i - SHORT) * spill_stride];
+    }
+};
+
+// ---- box-test side of a ray.  The slab test only has to be conservative (boxes are padded): it uses the
+// 1-ulp hardware reciprocal and (plane - o) * inv evaluated as fma(plane, inv, -o * inv).  Direction components smaller than
+// 1e-30 are clamped (sign kept) so that inv stays finite and no inf - inf can appear for axis-parallel rays.
+struct BoxRay {
+    f3 inv, oi;
+    uint32_t sx, sy, sz; // BVH4 only: 1 when the direction component is negative (near plane row = hi)
+};
+HD float box_dir(float d) { return (fabsf(d) < 1e-30f) ? copysignf(1e-30f, d) : d; }
+HD BoxRay box_ray(f3 o, f3 d)
+{
+    BoxRay r;
+    const f3 dd = V(box_dir(d.x), box_dir(d.y), box_dir(d.z));
+    r.inv = V(__builtin_amdgcn_rcpf(dd.x), __builtin_amdgcn_rcpf(dd.y), __builtin_amdgcn_rcpf(dd.z));
+    r.oi = V(-o.x * r.inv.x, -o.y * r.inv.y, -o.z * r.inv.z);
+    r.sx = dd.x < 0.0f ? 1u : 0u; r.sy = dd.y < 0.0f ? 1u : 0u; r.sz = dd.z < 0.0f ? 1u : 0u; // dead code in the BVH2 kernels
+    return r;
+}
+
+#define HJR_TRAV_DONE 0xffffffffu
+// One inner-node step: tests the children of node `cur` against [tmin, tfar], continues with the nearest hit child, pushes
+// the other hit children, or pops (HJR_TRAV_DONE when the stack is empty).  Returns the number of boxes tested.
+template <int WIDTH, int BLOCK, typename ST>
+HD uint32_t node_step(const float4* nodes, uint32_t& cur, const BoxRay& R, float tmin, float tfar, ST& stack, int& sp)
+{
+    if constexpr (WIDTH == 2) {
+    const float4* nd = nodes + cur * HJR_NODE2_F4;
+    const float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
+    const f3 inv = R.inv, oi = R.oi;
+    float t0 = fmaf(q0.x, inv.x, oi.x), t1 = fmaf(q0.w, inv.x, oi.x);
+    float lo0 = fminf(t0, t1), hi0 = fmaxf(t0, t1);
+    t0 = fmaf(q0.y, inv.y, oi.y); t1 = fmaf(q1.x, inv.y, oi.y);
+    lo0 = fmaxf(lo0, fminf(t0, t1)); hi0 = fminf(hi0, fmaxf(t0, t1));
+    t0 = fmaf(q0.z, inv.z, oi.z); t1 = fmaf(q1.y, inv.z, oi.z);
+    lo0 = fmaxf(lo0, fminf(t0, t1)); hi0 = fminf(hi0, fmaxf(t0, t1));
+    lo0 = fmaxf(lo0, tmin); hi0 = fminf(hi0, tfar);
+    t0 = fmaf(q1.z, inv.x, oi.x); t1 = fmaf(q2.y, inv.x, oi.x);
+    float lo1 = fminf(t0, t1), hi1 = fmaxf(t0, t1);
+    t0 = fmaf(q1.w, inv.y, oi.y); t1 = fmaf(q2.z, inv.y, oi.y);
+    lo1 = fmaxf(lo1, fminf(t0, t1)); hi1 = fminf(hi1, fmaxf(t0, t1));
+    t0 = fmaf(q2.x, inv.z, oi.z); t1 = fmaf(q2.w, inv.z, oi.z);
+    lo1 = fmaxf(lo1, fminf(t0, t1)); hi1 = fminf(hi1, fmaxf(t0, t1));
+    lo1 = fmaxf(lo1, tmin); hi1 = fminf(hi1, tfar);
+    const bool h0 = lo0 <= hi0, h1 = lo1 <= hi1; // conservative through the 2^-15 box padding (>= 16x the rounding error of t)
+    const uint32_t c0 = f2bits(q3.x), c1 = f2bits(q3.y);
+    if (h0 && h1) {
+        const bool swap = lo1 < lo0;
+        stack.put(sp, swap ? c0 : c1);
+        sp++;
+        cur = swap ? c1 : c0;
+    } else if (h0) cur = c0;
+    else if (h1) cur = c1;
+    else if (sp > 0) { sp--; cur = stack.get(sp); }
+    else cur = HJR_TRAV_DONE;
+    return 2u;
+    } else {
+    const float4* nd = nodes + cur * HJR_NODE4_F4;
+    const f3 inv = R.inv, oi = R.oi;
+    const float INF = bits2f(0x7f800000u);
+    // near / far plane rows picked by the ray's direction signs: no min/max per axis
+    const float4 nx = nd[0 + R.sx], fx = nd[1 - R.sx];
+    const float4 ny = nd[2 + R.sy], fy = nd[3 - R.sy];
+    const float4 nz = nd[4 + R.sz], fz = nd[5 - R.sz];
+    const float4 rr = nd[6];
+#define HJR_CHILD(c, C)                                                                                                  \
+    float tn##C = fmaxf(fmaxf(fmaf(nx.c, inv.x, oi.x), fmaf(ny.c, inv.y, oi.y)), fmaxf(fmaf(nz.c, inv.z, oi.z), tmin)); \
+    const float tf##C = fminf(fminf(fmaf(fx.c, inv.x, oi.x), fmaf(fy.c, inv.y, oi.y)), fminf(fmaf(fz.c, inv.z, oi.z), tfar)); \
+    const bool h##C = tn##C <= tf##C;                                                                                   \
+    tn##C = h##C ? tn##C : INF;
+    HJR_CHILD(x, 0) HJR_CHILD(y, 1) HJR_CHILD(z, 2) HJR_CHILD(w, 3)
+#undef HJR_CHILD
+    const uint32_t r0 = f2bits(rr.x), r1 = f2bits(rr.y), r2 = f2bits(rr.z), r3 = f2bits(rr.w);
+    const float m = fminf(fminf(tn0, tn1), fminf(tn2, tn3));
+    // nearest hit child first (ties: lowest slot); the other hit children are pushed in slot order
+    const int sel = (tn0 == m) ? 0 : ((tn1 == m) ? 1 : ((tn2 == m) ? 2 : 3));
+    if (h3 && sel != 3) { stack.put(sp, r3); sp++; }
+    if (h2 && sel != 2) { stack.put(sp, r2); sp++; }
+    if (h1 && sel != 1) { stack.put(sp, r1); sp++; }
+    if (h0 && sel != 0) { stack.put(sp, r0); sp++; }
+    if (h0 || h1 || h2 || h3) cur = (sel == 0) ? r0 : ((sel == 1) ? r1 : ((sel == 2) ? r2 : r3));
+    else if (sp > 0) { sp--; cur = stack.get(sp); }
+    else cur = HJR_TRAV_DONE;
+    return 4u;
+    }
+}
+
+struct Hit { float t, b1, b2; uint32_t k, prim; };
+
+// stack: this lane's column of the LDS stack, element i at stack[i * BLOCK]
+template <bool ANY, bool STATS, int WIDTH, int BLOCK, typename ST>
+HD bool traverse(const float4* nodes, const float4* tris, f3 o, f3 d, float tmin, float tmax, Hit& hit, ST& stack, Counters& cnt)
+{
+    const BoxRay R = box_ray(o, d);
+    int sp = 0;
+    uint32_t cur = 0;
+    hit.prim = 0xffffffffu;
+    hit.t = tmax;
+    for (;;) {
+        while (!(cur & HJR_LEAF_FLAG)) { // descend through inner nodes until this lane holds a leaf (or is done)
+            const uint32_t nb = node_step<WIDTH, BLOCK, ST>(nodes, cur, R, tmin, hit.t, stack, sp);
+            if (STATS) cnt.box += nb;
+        }
+        if (cur == HJR_TRAV_DONE) break;
+        const uint32_t first = cur & 0x07ffffffu, count = (cur >> 27) & 15u;
+        for (uint32_t i = 0; i < count; i++) {
+            const float4* g = tris + (first + i) * HJR_TRI_F4;
+            const float4 g0 = g[0], g1 = g[1], g2 = g[2];
+            float t, b1, b2;
+            if (STATS) cnt.tri++;
+            if (ray_tri(V(g0.x, g0.y, g0.z), V(g0.w, g1.x, g1.y), V(g1.z, g1.w, g2.x), o, d, tmin, tmax, t, b1, b2)) {
+                if (ANY) return true;
+                const uint32_t prim = f2bits(g2.y);
+                // order-independent closest-hit rule: smaller t wins; equal t -> smaller global prim id
+                if (hit.prim == 0xffffffffu || t < hit.t || (t == hit.t && prim < hit.prim)) {
+                    hit.t = t; hit.b1 = b1; hit.b2 = b2; hit.k = first + i; hit.prim = prim;
+                }
+            }
+        }
+        if (sp == 0) break;
+        sp--;
+        cur = stack.get(sp);
+    }
+    return hit.prim != 0xffffffffu;
+}
+
+// Fused traversal of two rays per lane in ONE loop: ray A = the pending NEE shadow ray of the bounce just shaded (any-hit),
+// ray B = the next closest-hit ray (continuation or a regenerated primary ray).  A lane moves on to B the moment its A is
+// resolved, without waiting for the rest of the wave, so the wave's trip count is max_lanes(tripsA + tripsB) instead of
+// max(tripsA) + max(tripsB) — the SIMT cost of per-lane trip-count variance drops by ~1/3 (profiles/r01_experiments.md).
+// Results are identical to two separate traversals.
+//
+// Straggler carry-over (CARRY > 0): the loop also ends when at most CARRY lanes are still traversing (and at least one
+// lane of this round has finished).  Those lanes keep their traversal state (TravCarry + hit + their LDS stack column),
+// skip the shading that follows and resume in the next round next to the other lanes' new rays: the wave's trip count per
+// round is set by the (64 - CARRY)-th slowest lane instead of the slowest one.  Per-lane results do not change.  The
+// threshold trades traversal lane-occupancy against shading lane-occupancy (profiles/r01_experiments.md): 8 for the
+// LDS-resident scenes (shading-heavy), 32 when nodes come from memory (traversal-heavy).
+#ifndef HJR_CARRY_LDS
+#define HJR_CARRY_LDS 8
+#endif
+#ifndef HJR_CARRY_MEM
+#define HJR_CARRY_MEM 32
+#endif
+struct TravCarry { uint32_t cur; int sp, phase; };
+template <bool STATS, int WIDTH, int BLOCK, typename ST, int CARRY>
+HD bool traverse_fused(const float4* nodes, const float4* tris, const bool a_valid, const f3 ao, const f3 ad, const float a_tmax, const bool b_valid,
+                       const f3 bo, const f3 bd, bool& occluded, Hit& hit, ST& stack, Counters& ca, Counters& cb, const bool resume, TravCarry& tc)
+{
+    const float tmin = 0.001f;
+    int phase, sp;
+    uint32_t cur;
+    if (CARRY > 0 && resume) { phase = tc.phase; sp = tc.sp; cur = tc.cur; } // occluded / hit are the caller's, kept across rounds
+    else {
+        occluded = false;
+        hit.prim = 0xffffffffu;
+        hit.t = 1e16f;
+        phase = a_valid ? 0 : (b_valid ? 1 : 2);
+        sp = 0;
+        cur = (phase < 2) ? 0u : HJR_TRAV_DONE;
+    }
+    f3 o = (phase == 0) ? ao : bo;
+    f3 d = (phase == 0) ? ad : bd;
+    BoxRay R = box_ray(o, d);
+    const int n_start = CARRY > 0 ? __popcll(__ballot(phase < 2)) : 0;
+#ifdef HJR_TIMING
+    unsigned long long t_node = 0, t_leaf = 0, t_last = __builtin_amdgcn_s_memtime();
+#endif
+    for (;;) {
+        if (CARRY > 0) {
+            const int n_act = __popcll(__ballot(phase < 2));
+            if (n_act == 0 || (n_act <= CARRY && n_act < n_start)) break;
+        } else if (__ballot(phase < 2) == 0ull) break;
+        if (phase < 2) {
+        // "while-while" traversal: every lane first descends through inner nodes until it holds a leaf (or is out of work) ...
+        while (!(cur & HJR_LEAF_FLAG)) {
+            const float tfar = (phase == 0) ? a_tmax : hit.t;
+            const uint32_t nb = node_step<WIDTH, BLOCK, ST>(nodes, cur, R, tmin, tfar, stack, sp);
+            if (STATS) { if (phase == 0) ca.box += nb; else cb.box += nb; }
+        }
+#ifdef HJR_TIMING
+        { __builtin_amdgcn_sched_barrier(0); unsigned long long now_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); t_node += now_ - t_last; t_last = now_; }
+#endif
+        // ... then all lanes test their leaf's triangles together
+        bool done = (cur == HJR_TRAV_DONE);
+        if (!done) {
+            const uint32_t first = cur & 0x07ffffffu, count = (cur >> 27) & 15u;
+            const float tri_tmax = (phase == 0) ? a_tmax : 1e16f;
+            for (uint32_t i = 0; i < count; i++) {
+                const float4* g = tris + (first + i) * HJR_TRI_F4;
+                const float4 g0 = g[0], g1 = g[1], g2 = g[2];
+                float t, b1, b2;
+                if (STATS) { if (phase == 0) ca.tri++; else cb.tri++; }
+                if (ray_tri(V(g0.x, g0.y, g0.z), V(g0.w, g1.x, g1.y), V(g1.z, g1.w, g2.x), o, d, tmin, tri_tmax, t, b1, b2)) {
+                    if (phase == 0) { occluded = true; done = true; break; }
+                    const uint32_t prim = f2bits(g2.y);
+                    // order-independent closest-hit rule: smaller t wins; equal t -> smaller global prim id
+                    if (hit.prim == 0xffffffffu || t < hit.t || (t == hit.t && prim < hit.prim)) {
+                        hit.t = t; hit.b1 = b1; hit.b2 = b2; hit.k = first + i; hit.prim = prim;
+                    }
+                }
+            }
+            if (!done) {
+                if (sp > 0) { sp--; cur = stack.get(sp); }
+                else done = true;
+            }
+        }
+        if (done) {
+            if (phase == 0 && b_valid) { // this lane's shadow ray is resolved: start its closest-hit ray right away
+                phase = 1;
+                o = bo; d = bd;
+                R = box_ray(o, d);
+                sp = 0; cur = 0;
+            } else { phase = 2; cur = HJR_TRAV_DONE; }
+        }
+#ifdef HJR_TIMING
+        { __builtin_amdgcn_sched_barrier(0); unsigned long long now_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); t_leaf += now_ - t_last; t_last = now_; }
+#endif
+    } }
+#ifdef HJR_TIMING
+    ca.t_node = t_node; ca.t_leaf = t_leaf;
+#endif
+    if (CARRY > 0) { tc.phase = phase; tc.sp = sp; tc.cur = cur; return phase < 2; }
+    return false;
+}

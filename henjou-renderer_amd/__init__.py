@@ -91,7 +91,8 @@ class Stats(C.Structure):
                                            "tri_tests_closest", "box_tests_shadow", "tri_tests_shadow",
                                            "shaded_hits", "light_samples", "nan_samples")] + \
                [("last_kernel_ms", C.c_float), ("bvh_nodes", C.c_uint32), ("bvh_depth", C.c_uint32),
-                ("n_triangles", C.c_uint32)]
+                ("n_triangles", C.c_uint32), ("lds_mode", C.c_uint32), ("stack_need", C.c_uint32),
+                ("stack_lds_entries", C.c_uint32), ("_reserved", C.c_uint32), ("stack_overflow_pushes", C.c_uint64)]
 
     def as_dict(self):
         return {n: (float(getattr(self, n)) if n == "last_kernel_ms" else int(getattr(self, n)))

@@ -284,7 +284,9 @@ template <int I, bool S, int W> static int launch_mem(hjr_ctx* c, const KParams&
 }
 template <int I, bool S, int W, bool A> static int launch_mem2(hjr_ctx* c, const KParams& kp, uint64_t n_items, hipStream_t st)
 {
-    const uint32_t lds_entries = kp.stack_depth < (uint32_t)HJR_SHORT_STACK ? kp.stack_depth : (uint32_t)HJR_SHORT_STACK;
+    uint32_t short_stack = HJR_SHORT_STACK;
+    if (const char* e = getenv("HJR_SHORT_STACK")) { int v = atoi(e); if (v >= 1 && v <= 64) short_stack = (uint32_t)v; } // tests force the overflow path with 2
+    const uint32_t lds_entries = kp.stack_depth < short_stack ? kp.stack_depth : short_stack;
     const size_t smem = (size_t)HJR_BLOCK * lds_entries * 4;
     auto kern = hjr_render_kernel<I, S, HJR_BLOCK, false, false, W, A>;
     int per_cu = 0;
@@ -304,6 +306,8 @@ template <int I, bool S, int W, bool A> static int launch_mem2(hjr_ctx* c, const
         c->d_spill.cap = spill_bytes;
     }
     k2.stack_spill = (uint32_t*)c->d_spill.p;
+    k2.stack_lds_entries = lds_entries;
+    c->stats.stack_lds_entries = lds_entries;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(HJR_BLOCK), smem, st, k2);
     return 0;
 }
@@ -324,7 +328,9 @@ static int render_impl(hjr_ctx* c, const hjr_params* p, void* d_color, void* d_a
     const uint64_t owned = (n_tiles > p->rank) ? (n_tiles - p->rank + world - 1) / world : 0;
     const uint32_t chunk_spp = hjr_chunk_spp(p->spp), n_chunks = hjr_n_chunks(p->spp);
     const uint64_t n_items = owned * n_chunks * 64;
-    if (n_items >= 0xffffffffull) { set_error("hjr_render: image too large"); return HJR_ERR_ARG; }
+    // the 32-bit queue head overshoots n_items by at most 64 per wave of the persistent grid (every wave stops fetching once it
+    // has seen the queue dry, hjr_kernel.hip.h); 2^24 covers 262 144 waves, far more than any resident grid
+    if (n_items >= 0xffffffffull - (1ull << 24)) { set_error("hjr_render: image too large (more than 2^32 - 2^24 work items per launch)"); return HJR_ERR_ARG; }
 
     // work area: [0] queue head, [16..] HJR_NSTAT uint64 counters
     const size_t work_bytes = 16 + (HJR_NSTAT + 20) * 8 + 32 + 512; // +20: phase clocks / lane-occupancy sums of the HJR_TIMING diagnostic build; +32: tile-class counters
@@ -342,8 +348,10 @@ static int render_impl(hjr_ctx* c, const hjr_params* p, void* d_color, void* d_a
 
     KParams kp;
     memset(&kp, 0, sizeof(kp));
+    kp.n_owned_tiles = (uint32_t)owned;
     if (n_chunks > 1) {
-        const size_t part_bytes = img_bytes * n_chunks;
+        // chunk sums of THIS rank's tiles only: [chunk][owned tile][64] float4 (1/world of the frame; allocated once per size)
+        const size_t part_bytes = (size_t)owned * 64u * 16u * n_chunks;
         DevBuf* pb[3] = { &c->d_part_color, &c->d_part_albedo, &c->d_part_normal };
         void* want[3] = { d_color, d_albedo, d_normal };
         for (int i = 0; i < 3; i++) {
@@ -393,6 +401,9 @@ static int render_impl(hjr_ctx* c, const hjr_params* p, void* d_color, void* d_a
     // node format / LDS staging were decided by the host builder for this frame (host/frame.cpp)
     int lds_mode = c->frame.lds_mode;
     if (lds_mode == 0 && c->frame.width == 2) lds_mode = 3;
+    c->stats.lds_mode = (uint32_t)lds_mode;
+    c->stats.stack_need = c->frame.stack_need;
+    c->stats.stack_lds_entries = 0; // set by the memory-path launch
     HIPCHK(hipEventRecord(c->ev0, st));
     // cost-ordered tile list (hjr_classify_tiles_kernel): HJR_TILE_ORDER=0 keeps the plain round-robin order
     static const bool tile_order_on = !(getenv("HJR_TILE_ORDER") && atoi(getenv("HJR_TILE_ORDER")) == 0);
@@ -404,7 +415,6 @@ static int render_impl(hjr_ctx* c, const hjr_params* p, void* d_color, void* d_a
             c->d_tiles.cap = 3 * tb;
             c->cost_tag = 0; // the classes of the previous frames went with the buffer
         }
-        kp.n_owned_tiles = (uint32_t)owned;
         kp.tile_order_w = (uint32_t*)c->d_tiles.p;
         kp.tile_class = (uint32_t*)((char*)c->d_tiles.p + tb);
         kp.tile_bucket = (uint32_t*)((char*)c->d_tiles.p + 2 * tb);
@@ -458,8 +468,8 @@ static int render_impl(hjr_ctx* c, const hjr_params* p, void* d_color, void* d_a
     if (lrc != 0) { set_error("hjr_render: could not reserve dynamic LDS for the BVH"); return HJR_ERR_DEVICE; }
     HIPCHK(hipGetLastError());
     if (n_chunks > 1) {
-        const size_t npix = (size_t)p->width * p->height;
-        unsigned fb = (unsigned)std::min<size_t>((npix + 255) / 256, (size_t)c->n_cus * 8);
+        const size_t n_slots = (size_t)owned * 64u;
+        unsigned fb = (unsigned)std::max<size_t>(1, std::min<size_t>((n_slots + 255) / 256, (size_t)c->n_cus * 8));
         hipLaunchKernelGGL(hjr_finalize_kernel, dim3(fb), dim3(256), 0, st, kp);
         HIPCHK(hipGetLastError());
     }
@@ -474,7 +484,8 @@ static int fetch_stats(hjr_ctx* c, hipStream_t st)
     HIPCHK(hipMemcpyAsync(h, (char*)c->d_work.p + 16, sizeof(h), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     uint64_t* dst = &c->stats.samples;
-    for (int i = 0; i < HJR_NSTAT; i++) dst[i] = h[i];
+    for (int i = 0; i < 10; i++) dst[i] = h[i];
+    c->stats.stack_overflow_pushes = h[10];
 #ifdef HJR_TIMING
     {
         unsigned long long tk[20];
@@ -591,6 +602,21 @@ extern "C" int hjr_render_denoised(hjr_ctx* c, const hjr_params* p, int render_m
     HIPCHK(hipMemcpyAsync(out, c->d_dn_out.p, out_bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return HJR_OK;
+}
+
+// Round-trips every child ref the builder can emit for a tree that host/frame.cpp admits to the 16-bit-stack layout
+// (inner node ids < HJR_STACK16_MAX_NODES; leaves of 0..HJR_STACK16_LEAF_MAX triangles starting below HJR_STACK16_MAX_TRIS)
+// through stack_enc<uint16_t> / stack_dec.  Pure host code (the same inline functions the kernel uses); 0 = all refs survive.
+extern "C" int hjr_selftest_stack16(void)
+{
+    for (uint32_t n = 0; n < HJR_STACK16_MAX_NODES; n++)
+        if (stack_dec(stack_enc<uint16_t>(n)) != n) return 1;
+    for (uint32_t count = 0; count <= HJR_STACK16_LEAF_MAX; count++)
+        for (uint32_t first = 0; first < HJR_STACK16_MAX_TRIS; first++) {
+            const uint32_t ref = HJR_LEAF_FLAG | (count << 27) | first;
+            if (stack_dec(stack_enc<uint16_t>(ref)) != ref) return 2;
+        }
+    return 0;
 }
 
 extern "C" int hjr_synchronize(hjr_ctx* c)

@@ -170,12 +170,13 @@ template <int INTEGRATOR, bool STATS, int BLOCK, bool LDSBVH, bool STACK16, int 
 __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_render_kernel(const KParams P)
 {
     typedef typename std::conditional<STACK16, uint16_t, uint32_t>::type SE; // stack entry type
-    constexpr int SHORT = LDSBVH ? 0 : HJR_SHORT_STACK;
-    typedef LaneStack<SE, BLOCK, SHORT> ST;
+    typedef LaneStack<SE, BLOCK, !LDSBVH, STATS> ST;
     ST stack;
+    stack.n_over = 0;
     stack.lds = reinterpret_cast<SE*>(hjr_smem) + threadIdx.x;
     stack.spill = P.stack_spill + (blockIdx.x * BLOCK + threadIdx.x);
     stack.spill_stride = P.spill_stride;
+    stack.lds_n = (int)P.stack_lds_entries;
     const uint32_t lane = threadIdx.x & 63u;
     const float4* nodes = P.nodes;
     const float4* tris = P.tri_geom;
@@ -216,6 +217,7 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
     uint32_t item = 0;          // px | py << 13 | chunk << 26
     uint32_t s = 0;
     uint32_t w_next = 0, w_end = 0; // this wave's private item range (wave-uniform)
+    bool exhausted = false;         // wave-uniform: the global queue has run dry
     uint32_t it_cost = 0;           // closest-hit rays traced for the current item
     f3 sumL = V1(0.0f), sumA = V1(0.0f), sumN = V1(0.0f);
     f3 sh_d = V1(0.0f), sh_contrib = V1(0.0f);
@@ -274,8 +276,10 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
                 P.aov_color[pix] = make_float4(sumL.x * inv_spp, sumL.y * inv_spp, sumL.z * inv_spp, 1.0f);
                 if (AOVS && P.aov_albedo) P.aov_albedo[pix] = make_float4(sumA.x * inv_spp, sumA.y * inv_spp, sumA.z * inv_spp, 1.0f);
                 if (AOVS && P.aov_normal) P.aov_normal[pix] = make_float4(sumN.x * inv_spp, sumN.y * inv_spp, sumN.z * inv_spp, 1.0f);
-            } else { // chunk sum -> HBM; hjr_finalize_kernel adds the chunks of a pixel in chunk order
-                const size_t slot = (size_t)HJR_CHUNK * ((size_t)P.width * P.height) + pix;
+            } else { // chunk sum -> HBM; hjr_finalize_kernel adds the chunks of a pixel in chunk order.  The buffers hold this rank's
+                     // tiles only: slot = ((chunk * owned tiles) + owned tile index) * 64 + pixel in tile
+                const uint32_t otile = ((HJR_PY / HJR_TILE) * P.tiles_x + HJR_PX / HJR_TILE) / P.world;
+                const size_t slot = ((size_t)HJR_CHUNK * P.n_owned_tiles + otile) * 64u + ((HJR_PY & 7u) * 8u + (HJR_PX & 7u));
                 P.part_color[slot] = make_float4(sumL.x, sumL.y, sumL.z, 0.0f);
                 if (AOVS && P.part_albedo) P.part_albedo[slot] = make_float4(sumA.x, sumA.y, sumA.z, 0.0f);
                 if (AOVS && P.part_normal) P.part_normal[slot] = make_float4(sumN.x, sumN.y, sumN.z, 0.0f);
@@ -315,12 +319,22 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
                 uint32_t q = w_next + prefix;          // wave-uniform w_next / w_end
                 const uint32_t have = w_end - w_next;  // items left in the private range
                 if (n > have) {                        // not enough: lanes beyond `have` come from a fresh range
-                    uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(P.queue_head, 64u);
-                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                    if (prefix >= have) q = base + (prefix - have);
-                    w_next = base + (n - have);
-                    w_end = base + 64u;
+                    // once a wave has seen the queue run dry it never touches the head again (wave-uniform flag): the 32-bit head
+                    // overshoots n_owned_items by at most 64 per wave of the grid and cannot wrap (hjr_device.hip keeps that margin)
+                    uint32_t base = 0xffffffffu;
+                    if (!exhausted) {
+                        if (lane == 0) base = atomicAdd(P.queue_head, 64u);
+                        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                        exhausted = base >= P.n_owned_items;
+                    }
+                    if (exhausted) {
+                        if (prefix >= have) q = 0xffffffffu;
+                        w_next = w_end = 0u;
+                    } else {
+                        if (prefix >= have) q = base + (prefix - have);
+                        w_next = base + (n - have);
+                        w_end = base + 64u;
+                    }
                 } else w_next += n;
                 // measured cost of a tile (orders the tiles of the next frame, hjr_cost_hist_kernel): a lane sums the rays of its
                 // consecutive items of one tile and flushes when it moves on; lanes leaving the same tile together (the usual
@@ -547,6 +561,7 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
 #endif
 
     if (STATS) {
+        lc[10] = stack.n_over;
         for (int i = 0; i < HJR_NSTAT; i++) {
             unsigned long long v = lc[i];
             for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
@@ -565,10 +580,10 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
 template <int WIDTH>
 __global__ void __launch_bounds__(64) hjr_classify_tiles_kernel(const KParams P)
 {
-    typedef LaneStack<uint32_t, 64, 0> ST;
+    typedef LaneStack<uint32_t, 64, false> ST;
     ST stack;
     stack.lds = reinterpret_cast<uint32_t*>(hjr_smem) + threadIdx.x;
-    stack.spill = nullptr; stack.spill_stride = 0;
+    stack.spill = nullptr; stack.spill_stride = 0; stack.lds_n = 0; stack.n_over = 0;
     uint32_t n_cls[4] = { 0u, 0u, 0u, 0u }; // per block; one atomic per class at the end (32 k atomics on four words cost 0.4 ms)
     for (uint32_t idx = blockIdx.x; idx < P.n_owned_tiles; idx += gridDim.x) {
         const uint32_t tile = idx * P.world + P.rank;
@@ -661,21 +676,22 @@ __global__ void __launch_bounds__(256) hjr_cost_scatter_kernel(const KParams P)
 
 // Adds the chunk sums of every owned pixel in chunk order and scales by 1/spp: a fixed summation
 // tree, so the frame is bitwise independent of which lane/wave/GPU rendered which chunk.  Streaming kernel: one lane
-// per pixel, n_chunks coalesced float4 loads, one float4 store.
+// per pixel of an owned tile, n_chunks coalesced float4 loads ([chunk][owned tile][64] layout), one float4 store.
 __global__ void __launch_bounds__(256) hjr_finalize_kernel(const KParams P)
 {
-    const size_t npix = (size_t)P.width * P.height;
+    const size_t n_slots = (size_t)P.n_owned_tiles * 64u; // chunk-sum slots per chunk: 64 per owned tile
     const float inv_spp = 1.0f / (float)P.spp;
-    for (size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x; pix < npix; pix += (size_t)gridDim.x * blockDim.x) {
-        const uint32_t x = (uint32_t)(pix % P.width), y = (uint32_t)(pix / P.width);
-        const uint32_t tile = (y / HJR_TILE) * P.tiles_x + (x / HJR_TILE);
-        if (tile % P.world != P.rank) continue;
+    for (size_t sl = (size_t)blockIdx.x * blockDim.x + threadIdx.x; sl < n_slots; sl += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t tile = (uint32_t)(sl >> 6) * P.world + P.rank;
+        const uint32_t x = (tile % P.tiles_x) * HJR_TILE + ((uint32_t)sl & 7u), y = (tile / P.tiles_x) * HJR_TILE + (((uint32_t)sl >> 3) & 7u);
+        if (x >= P.width || y >= P.height) continue;
+        const size_t pix = (size_t)y * P.width + x;
         float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f), b = a, c = a;
         for (uint32_t k = 0; k < P.n_chunks; k++) {
-            const float4 v = P.part_color[(size_t)k * npix + pix];
+            const float4 v = P.part_color[(size_t)k * n_slots + sl];
             a.x = a.x + v.x; a.y = a.y + v.y; a.z = a.z + v.z;
-            if (P.aov_albedo) { const float4 w = P.part_albedo[(size_t)k * npix + pix]; b.x = b.x + w.x; b.y = b.y + w.y; b.z = b.z + w.z; }
-            if (P.aov_normal) { const float4 w = P.part_normal[(size_t)k * npix + pix]; c.x = c.x + w.x; c.y = c.y + w.y; c.z = c.z + w.z; }
+            if (P.aov_albedo) { const float4 w = P.part_albedo[(size_t)k * n_slots + sl]; b.x = b.x + w.x; b.y = b.y + w.y; b.z = b.z + w.z; }
+            if (P.aov_normal) { const float4 w = P.part_normal[(size_t)k * n_slots + sl]; c.x = c.x + w.x; c.y = c.y + w.y; c.z = c.z + w.z; }
         }
         P.aov_color[pix] = make_float4(a.x * inv_spp, a.y * inv_spp, a.z * inv_spp, 1.0f);
         if (P.aov_albedo) P.aov_albedo[pix] = make_float4(b.x * inv_spp, b.y * inv_spp, b.z * inv_spp, 1.0f);

@@ -44,7 +44,7 @@
  *   pdf = float(1.0 / area) * (1.0f / light_prim_count) */
 #define HJR_LIGHT_F4 6
 
-#define HJR_NSTAT 10 /* order of hjr_stats' uint64 counters */
+#define HJR_NSTAT 11 /* hjr_stats' ten leading uint64 counters in order, then [10] = stack_overflow_pushes */
 
 /* Work-item chunking: a pixel's spp samples are cut into n_chunks runs of chunk_spp consecutive samples
  * (a multiple of 8, at most 64 runs); pixel mean = ((c0 + c1) + ... ) * (1/spp), ck = in-order sum of run k.  Depends on spp

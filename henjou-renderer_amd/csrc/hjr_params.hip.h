@@ -44,6 +44,7 @@ struct KParams {
     uint32_t* cost_hist;             // [0..63] tiles per cost bucket, [64..127] scatter cursors
     uint32_t cost_div;               // 64 * spp: rays per tile at one ray per sample
     uint32_t spill_stride;           // lanes in the grid
+    uint32_t stack_lds_entries;      // memory-path kernels: stack entries per lane kept in LDS (the rest overflow to stack_spill)
     float4* part_color;              // [n_chunks][height][width] chunk sums when n_chunks > 1
     float4* part_albedo;
     float4* part_normal;

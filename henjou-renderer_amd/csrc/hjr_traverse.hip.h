@@ -39,41 +39,50 @@ HD bool ray_tri(f3 v0, f3 v1, f3 v2, f3 o, f3 d, float tmin, float tmax, float& 
 // ---- per-lane traversal stack in LDS, element i of this lane at stack[i * BLOCK] (conflict-free columns).  Small scenes that
 // are staged into LDS use 16-bit entries (node index < 32768, or leaf: bit15 | count << 13 | first triangle < 8192), which
 // halves the stack's LDS footprint; everything else uses the 32-bit child refs as they are.
-template <typename ST> HD ST stack_enc(uint32_t ref);
-template <> HD uint32_t stack_enc<uint32_t>(uint32_t ref) { return ref; }
-template <> HD uint16_t stack_enc<uint16_t>(uint32_t ref)
+// The 16-bit form holds leaves of at most HJR_STACK16_LEAF_MAX triangles (2-bit count): host/frame.cpp only selects it
+// for such trees, and hjr_selftest_stack16 (csrc/hjr_device.hip) round-trips every ref the builder can emit.
+#define HJR_STACK16_LEAF_MAX 3u
+#define HJR_STACK16_MAX_TRIS 8192u
+#define HJR_STACK16_MAX_NODES 32768u
+#define HDH __host__ __device__ __forceinline__
+template <typename ST> HDH ST stack_enc(uint32_t ref);
+template <> HDH uint32_t stack_enc<uint32_t>(uint32_t ref) { return ref; }
+template <> HDH uint16_t stack_enc<uint16_t>(uint32_t ref)
 {
     return (uint16_t)((ref & HJR_LEAF_FLAG) ? (0x8000u | (((ref >> 27) & 3u) << 13) | (ref & 0x1fffu)) : ref);
 }
-HD uint32_t stack_dec(uint32_t r) { return r; }
-HD uint32_t stack_dec(uint16_t r16)
+HDH uint32_t stack_dec(uint32_t r) { return r; }
+HDH uint32_t stack_dec(uint16_t r16)
 {
     const uint32_t r = r16;
     return (r & 0x8000u) ? (HJR_LEAF_FLAG | (((r >> 13) & 3u) << 27) | (r & 0x1fffu)) : r;
 }
 
-// One lane's traversal stack.  SHORT == 0: every entry in LDS (column of this lane).  SHORT > 0 (kernels that read the BVH from
-// memory): only the top-of-tree SHORT entries are in LDS, deeper ones overflow into a per-lane column of a global buffer
-// ([level][lane], coalesced when neighbouring lanes overflow together).  The exact worst-case depth of a BVH4 over a million
-// triangles is ~46 entries, traversal rarely needs more than a dozen: with the whole stack in LDS the stacks, not the
-// registers, capped the occupancy at 3 workgroups per CU.
+// One lane's traversal stack.  SPILL == false: every entry in LDS (column of this lane).  SPILL == true (kernels that read the
+// BVH from memory): only the top-of-tree `lds_n` entries are in LDS, deeper ones overflow into a per-lane column of a global
+// buffer ([level][lane], coalesced when neighbouring lanes overflow together).  The exact worst-case depth of a BVH4 over a
+// million triangles is ~46 entries, traversal rarely needs more than a dozen: with the whole stack in LDS the stacks, not the
+// registers, capped the occupancy at 3 workgroups per CU.  lds_n is a launch parameter (wave-uniform, an SGPR compare):
+// HJR_SHORT_STACK entries unless the environment overrides it (tests force the overflow path with HJR_SHORT_STACK=2).
 #ifndef HJR_SHORT_STACK
 #define HJR_SHORT_STACK 16
 #endif
-template <typename E, int BLOCK_, int SHORT>
+template <typename E, int BLOCK_, bool SPILL, bool COUNT = false>
 struct LaneStack {
     E* lds;
     uint32_t* spill;
     uint32_t spill_stride;
+    int lds_n;
+    uint32_t n_over; // COUNT (the counting kernel variant) only: pushes that went to the overflow buffer
     HD void put(int i, uint32_t ref)
     {
-        if (SHORT == 0 || i < SHORT) lds[i * BLOCK_] = stack_enc<E>(ref);
-        else spill[(size_t)(i - SHORT) * spill_stride] = ref;
+        if (!SPILL || i < lds_n) lds[i * BLOCK_] = stack_enc<E>(ref);
+        else { spill[(size_t)(i - lds_n) * spill_stride] = ref; if (COUNT) n_over++; }
     }
     HD uint32_t get(int i) const
     {
-        if (SHORT == 0 || i < SHORT) return stack_dec(lds[i * BLOCK_]);
-        return spill[(size_t)(i - SHORT) * spill_stride];
+        if (!SPILL || i < lds_n) return stack_dec(lds[i * BLOCK_]);
+        return spill[(size_t)(i - lds_n) * spill_stride];
     }
 };
 

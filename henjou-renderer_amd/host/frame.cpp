@@ -529,8 +529,12 @@ bool build_frame(const SceneCopy& sc, const float* M, const float* Mi, uint32_t 
     const size_t stack2 = (size_t)B.max_depth + 2;
     int lds_mode = 0;
     if (allow_lds) {
-        if ((size_t)HJR_BLOCK_LDS * stack2 * 4 + 16 + bvh2_bytes + table_bytes <= HJR_LDS_BUDGET) lds_mode = 1;
-        else if ((size_t)HJR_BLOCK_LDS * stack2 * 2 + 16 + bvh2_bytes + table_bytes <= HJR_LDS_BUDGET && n_inner2 < 32768u && n < 8192u) lds_mode = 2;
+        // 16-bit stack entries hold leaves of at most 3 triangles below triangle 8192 and node ids below 32768 (hjr_traverse.hip.h)
+        const bool fits16 = (size_t)HJR_BLOCK_LDS * stack2 * 2 + 16 + bvh2_bytes + table_bytes <= HJR_LDS_BUDGET && n_inner2 < 32768u && n < 8192u && B.leaf_max <= 3u;
+        const bool prefer16 = getenv("HJR_LDS_STACK16") && atoi(getenv("HJR_LDS_STACK16")) != 0; // test / tuning knob: 16-bit entries whenever they fit
+        if (fits16 && prefer16) lds_mode = 2;
+        else if ((size_t)HJR_BLOCK_LDS * stack2 * 4 + 16 + bvh2_bytes + table_bytes <= HJR_LDS_BUDGET) lds_mode = 1;
+        else if (fits16) lds_mode = 2;
     }
     if (const char* e = getenv("HJR_BVH_WIDTH")) { // tuning knob: force a node format (forcing 4 also forces the memory path)
         int v = atoi(e);

@@ -328,7 +328,7 @@ bool load_gltf(const std::string& dir, const std::string& file, SceneData& sc, h
         const Json& j = m.json;
         const Json* nodes = j.find("nodes");
         size_t n_nodes = nodes ? nodes->size() : 0;
-        std::vector<Animation> animation(n_nodes); // gltfloader.h:1120-1121
+        std::vector<NodeMotion> animation(n_nodes); // gltfloader.h:1120-1121
 
         // ---- materials (gltfloader.h:1125-1267).  tinygltf defaults: baseColorFactor 1, metallic 1, roughness 1, emissive 0.
         std::map<std::string, int> known_tex;
@@ -385,16 +385,13 @@ bool load_gltf(const std::string& dir, const std::string& file, SceneData& sc, h
         // ---- nodes: TRS as key 0, mesh nodes de-indexed, camera node (gltfloader.h:1308-1531)
         for (size_t node_index = 0; node_index < n_nodes; node_index++) {
             const Json& node = nodes->at(node_index);
-            Animation& na = animation[node_index];
-            na.translation_data.key.push_back(0);
-            na.rotation_data.key.push_back(0);
-            na.scale_data.key.push_back(0);
+            NodeMotion& na = animation[node_index];
             const Json* t = node.find("translation");
             const Json* r = node.find("rotation");
             const Json* s = node.find("scale");
-            na.translation_data.data.push_back(t && t->size() ? float3_{ (float)t->at(0).num, (float)t->at(1).num, (float)t->at(2).num } : float3_{ 0, 0, 0 });
-            na.rotation_data.data.push_back(r && r->size() ? float4_{ (float)r->at(0).num, (float)r->at(1).num, (float)r->at(2).num, (float)r->at(3).num } : float4_{ 0, 0, 0, 1 });
-            na.scale_data.data.push_back(s && s->size() ? float3_{ (float)s->at(0).num, (float)s->at(1).num, (float)s->at(2).num } : float3_{ 1, 1, 1 });
+            na.translation.push(0, t && t->size() ? float3_{ (float)t->at(0).num, (float)t->at(1).num, (float)t->at(2).num } : float3_{ 0, 0, 0 });
+            na.rotation.push(0, r && r->size() ? float4_{ (float)r->at(0).num, (float)r->at(1).num, (float)r->at(2).num, (float)r->at(3).num } : float4_{ 0, 0, 0, 1 });
+            na.scale.push(0, s && s->size() ? float3_{ (float)s->at(0).num, (float)s->at(1).num, (float)s->at(2).num } : float3_{ 1, 1, 1 });
 
             int mesh = (int)node.int_or("mesh", -1);
             int camera = (int)node.int_or("camera", -1);
@@ -506,25 +503,25 @@ bool load_gltf(const std::string& dir, const std::string& file, SceneData& sc, h
                     const unsigned char *kp, *dp;
                     size_t kstride, kcount, dstride, dcount;
                     m.span((int)sampler.at("input").as_int(), kp, kstride, kcount, 4);
-                    Animation& a = animation[(size_t)target_node];
+                    NodeMotion& a = animation[(size_t)target_node];
                     auto key_at = [&](size_t k) -> float {
                         if (k >= kcount) throw JsonError("Tried to access beyond the last element of an array adapter");
                         return rd<float>(kp + k * kstride);
                     };
                     if (path == "translation" || path == "scale") {
                         m.span((int)sampler.at("output").as_int(), dp, dstride, dcount, 12);
-                        AnimationData<float3_>& d = (path == "translation") ? a.translation_data : a.scale_data;
+                        Track<float3_>& d = (path == "translation") ? a.translation : a.scale;
                         for (size_t k = 0; k < dcount; k++) {
                             const unsigned char* p = dp + k * dstride;
-                            d.data.push_back({ rd<float>(p), rd<float>(p + 4), rd<float>(p + 8) });
-                            d.key.push_back(key_at(k));
+                            const float3_ v = { rd<float>(p), rd<float>(p + 4), rd<float>(p + 8) }; // the value is read before its key, as in the reference
+                            d.push(key_at(k), v);
                         }
                     } else if (path == "rotation") {
                         m.span((int)sampler.at("output").as_int(), dp, dstride, dcount, 16);
                         for (size_t k = 0; k < dcount; k++) {
                             const unsigned char* p = dp + k * dstride;
-                            a.rotation_data.data.push_back({ rd<float>(p), rd<float>(p + 4), rd<float>(p + 8), rd<float>(p + 12) });
-                            a.rotation_data.key.push_back(key_at(k));
+                            const float4_ v = { rd<float>(p), rd<float>(p + 4), rd<float>(p + 8), rd<float>(p + 12) };
+                            a.rotation.push(key_at(k), v);
                         }
                     }
                 }
@@ -567,9 +564,7 @@ void affine_inverse_3x4(const float* m, float* inv)
 void eval_transforms(const SceneData& sc, float time, float* m12, float* inv12) // renderer.h:257-291
 {
     for (size_t i = 0; i < sc.instances.size(); i++) {
-        const Animation& anim = sc.animations[sc.instances[i].animation_id];
-        Affine4x4 affine = anim.getAnimationAffine(time);
-        for (int k = 0; k < 12; k++) m12[i * 12 + k] = affine[k];
+        sc.animations[sc.instances[i].animation_id].matrix3x4(time, m12 + i * 12);
         affine_inverse_3x4(m12 + i * 12, inv12 + i * 12);
     }
 }
@@ -581,15 +576,19 @@ void eval_camera(const SceneData& sc, const hjr_render_option& o, float time, hj
     float3_ cdir = { o.camera_direction[0], o.camera_direction[1], o.camera_direction[2] };
     float3_ pos, dir, up, right;
     if (o.camera_animation_id != -1 && o.allow_camera_animation && (size_t)o.camera_animation_id < sc.animations.size()) {
-        const Animation& anim = sc.animations[(size_t)o.camera_animation_id];
-        Affine4x4 affine_pos = anim.getAnimationAffine(time);
-        Affine4x4 affine_dir = anim.getRotateAnimationAffine(time);
-        float4_ p = affine_pos * float4_{ cpos.x, cpos.y, cpos.z, 1.0f };
-        float4_ d = affine_dir * float4_{ cdir.x, cdir.y, cdir.z, 0.0f };
-        float4_ u = affine_dir * float4_{ 0, 1, 0, 0.0f };
-        pos = { p.x, p.y, p.z };
-        dir = { d.x, d.y, d.z };
-        up = { u.x, u.y, u.z };
+        // camera node: position through the node's T*R*S, direction and up through its rotation alone (w = 0); the products with
+        // the matrices' constant last column / w component are kept (matrix.h:58-65 forms all four per row)
+        const NodeMotion& node = sc.animations[(size_t)o.camera_animation_id];
+        float m[12], r[3][3];
+        node.matrix3x4(time, m);
+        node.rotation3x3(time, r);
+        auto point = [&](const float3_& v) { return float3_{ v.x * m[0] + v.y * m[1] + v.z * m[2] + 1.0f * m[3], v.x * m[4] + v.y * m[5] + v.z * m[6] + 1.0f * m[7],
+                                                             v.x * m[8] + v.y * m[9] + v.z * m[10] + 1.0f * m[11] }; };
+        auto vector = [&](const float3_& v) { return float3_{ v.x * r[0][0] + v.y * r[0][1] + v.z * r[0][2] + 0.0f * 0.0f, v.x * r[1][0] + v.y * r[1][1] + v.z * r[1][2] + 0.0f * 0.0f,
+                                                              v.x * r[2][0] + v.y * r[2][1] + v.z * r[2][2] + 0.0f * 0.0f }; };
+        pos = point(cpos);
+        dir = vector(cdir);
+        up = vector(float3_{ 0, 1, 0 });
         right = normalize3(cross3(dir, up));
     } else {
         pos = cpos;

@@ -1,8 +1,9 @@
-// Host-side scene model: mirrors the reference's SceneData / Material / Animation / RenderOption
-// (renderer/scene.h:9-36, renderer/material.h:10-63, renderer/animation.h:20-94, renderer/render_option.h:45-84)
-// so that the loaders and the frame set-up read like the reference's.  All arithmetic is fp32 in the
-// reference's evaluation order (this translation unit is compiled with -ffp-contract=off).
+// Host-side scene model: the data of the reference's SceneData / Material / RenderOption (renderer/scene.h:9-36,
+// renderer/material.h:10-63, renderer/render_option.h:45-84) and the node motion that renderer/animation.h:20-131 and
+// common/matrix.h:6-104 evaluate per frame.  All arithmetic is fp32 in the reference's evaluation order (every translation
+// unit that includes this header is compiled with -ffp-contract=off).
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <string>
@@ -32,103 +33,82 @@ inline float3_ normalize3(const float3_& v) // sutil/vec_math.h normalize: v * (
     return v * invLen;
 }
 
-// common/matrix.h:6-19 — row-major 4x4
-struct Affine4x4 {
-    float v[16];
-    Affine4x4() { for (float& f : v) f = 0; }
-    float operator[](int i) const { return v[i]; }
-};
-inline Affine4x4 translateAffine(const float3_& t) // matrix.h:21-24
-{
-    Affine4x4 a;
-    const float v[16] = { 1, 0, 0, t.x, 0, 1, 0, t.y, 0, 0, 1, t.z, 0, 0, 0, 1 };
-    for (int i = 0; i < 16; i++) a.v[i] = v[i];
-    return a;
-}
-inline Affine4x4 scaleAffine(const float3_& s) // matrix.h:26-29
-{
-    Affine4x4 a;
-    const float v[16] = { s.x, 0, 0, 0, 0, s.y, 0, 0, 0, 0, s.z, 0, 0, 0, 0, 1 };
-    for (int i = 0; i < 16; i++) a.v[i] = v[i];
-    return a;
-}
-inline Affine4x4 rotateAffine(const float4_& q) // matrix.h:32-56 (the `2.0 *` products are evaluated in double there)
-{
-    float q2xy = (float)(2.0 * q.x * q.y);
-    float q2xz = (float)(2.0 * q.x * q.z);
-    float q2xw = (float)(2.0 * q.x * q.w);
-    float q2yz = (float)(2.0 * q.y * q.z);
-    float q2yw = (float)(2.0 * q.y * q.w);
-    float q2zw = (float)(2.0 * q.z * q.w);
-    float q2ww = (float)(2.0 * q.w * q.w);
-    Affine4x4 a;
-    const float v[16] = { q2ww + 2.0f * q.x * q.x - 1.0f, q2xy - q2zw, q2xz + q2yw, 0,
-                          q2xy + q2zw, q2ww + 2.0f * q.y * q.y - 1.0f, q2yz - q2xw, 0,
-                          q2xz - q2yw, q2yz + q2xw, q2ww + 2.0f * q.z * q.z - 1.0f, 0,
-                          0, 0, 0, 1 };
-    for (int i = 0; i < 16; i++) a.v[i] = v[i];
-    return a;
-}
-inline float4_ operator*(const Affine4x4& a, const float4_& p) // matrix.h:58-65
-{
-    return { p.x * a[0] + p.y * a[1] + p.z * a[2] + p.w * a[3], p.x * a[4] + p.y * a[5] + p.z * a[6] + p.w * a[7],
-             p.x * a[8] + p.y * a[9] + p.z * a[10] + p.w * a[11], p.x * a[12] + p.y * a[13] + p.z * a[14] + p.w * a[15] };
-}
-inline Affine4x4 operator*(const Affine4x4& a, const Affine4x4& b) // matrix.h:67-76
-{
-    Affine4x4 r;
-    for (int j = 0; j < 4; j++)
-        for (int i = 0; i < 4; i++)
-            r.v[i + j * 4] = a[0 + j * 4] * b[i + 0 * 4] + a[1 + j * 4] * b[i + 1 * 4] + a[2 + j * 4] * b[i + 2 * 4] + a[3 + j * 4] * b[i + 3 * 4];
-    return r;
-}
+// ---- node motion: keyframe tracks -> per-frame instance matrix.
+// What must match the reference bit for bit is the VALUE of every matrix entry (common/matrix.h:21-76 builds T, R and S as
+// 4x4 matrices and multiplies them; renderer/animation.h:42-103 samples the keys), not its data structures.  Here a node
+// keeps three keyframe tracks and writes the 3x4 matrix the kernel-side layout wants directly; every entry is the same
+// left-to-right sum of the same four products the 4x4 multiplications form (zero and one factors included, so signed zeros
+// and non-finite inputs propagate identically).
 
-// renderer/animation.h:20-32
-template <typename T> struct AnimationData {
-    std::vector<T> data;
-    std::vector<float> key;
+// One animated channel of a node.  Key 0 is the node's static TRS at time 0; the glTF channels are appended behind it
+// (gltfloader.h:1313-1343, 1536-1590).  Sampling is linear for every sampler (the glTF "interpolation" field is never read)
+// and component-wise, also for quaternions, which are NOT re-normalised (animation.h:70-79).
+template <typename V> struct Track {
+    std::vector<float> times;
+    std::vector<V> values;
+    void push(float t, const V& v) { times.push_back(t); values.push_back(v); }
+    bool empty() const { return times.empty(); }
+    // animation.h:42-67.  `next` = number of keys <= time (the reference's hand-written bisection is exactly this
+    // upper bound).  Quirk kept on purpose: with several keys and 0 <= time < times[0] the reference's `offset = next - 1`
+    // is -1, wraps in its unsigned comparison and selects the LAST key, the same as a time past the end.
+    V at(float time) const
+    {
+        if (times.size() == 1 || time < 0) return values[0];
+        const size_t next = (size_t)(std::upper_bound(times.begin(), times.end(), time, [](float t, float key) { return !(key <= t); }) - times.begin());
+        const bool before_first_key = next == 0, at_or_past_last_key = next >= times.size();
+        if (before_first_key || at_or_past_last_key) return values[times.size() - 1];
+        const size_t k = next - 1;
+        const float w = (time - times[k]) / (times[k + 1] - times[k]);
+        return values[k] * (1.0f - w) + values[k + 1] * w;
+    }
 };
 
-// renderer/animation.h:34-131.  Interpolation is LINEAR for every sampler (the glTF "interpolation" field is never
-// read, gltfloader.h:1538-1588) and quaternions are lerped without re-normalisation (animation.h:70-79).
-struct Animation {
-    AnimationData<float3_> translation_data;
-    AnimationData<float4_> rotation_data;
-    AnimationData<float3_> scale_data;
+struct NodeMotion {
+    Track<float3_> translation;
+    Track<float4_> rotation;
+    Track<float3_> scale;
 
-    template <typename T> static T animationInterpolate(const std::vector<T>& animation, const std::vector<float>& key, float time)
-    { // animation.h:42-67
-        if (key.size() == 1 || time < 0) return animation[0];
-        int first = 0, len = (int)key.size();
-        while (len > 0) {
-            int half = len >> 1, middle = first + half;
-            if (key[middle] <= time) { first = middle + 1; len -= half + 1; }
-            else len = half;
+    // rotation block of matrix.h:32-56: the `2.0 * a * b` products are double expressions there, rounded to float once
+    static void rotation_rows(const float4_& q, float r[3][3])
+    {
+        const float xy = (float)(2.0 * q.x * q.y), xz = (float)(2.0 * q.x * q.z), xw = (float)(2.0 * q.x * q.w);
+        const float yz = (float)(2.0 * q.y * q.z), yw = (float)(2.0 * q.y * q.w), zw = (float)(2.0 * q.z * q.w);
+        const float ww = (float)(2.0 * q.w * q.w);
+        r[0][0] = ww + 2.0f * q.x * q.x - 1.0f; r[0][1] = xy - zw;                       r[0][2] = xz + yw;
+        r[1][0] = xy + zw;                       r[1][1] = ww + 2.0f * q.y * q.y - 1.0f; r[1][2] = yz - xw;
+        r[2][0] = xz - yw;                       r[2][1] = yz + xw;                       r[2][2] = ww + 2.0f * q.z * q.z - 1.0f;
+    }
+    // Rows 0..2 of (T * R) * S (animation.h:81-94: no node hierarchy), written as a row-major 3x4.
+    void matrix3x4(float time, float out[12]) const
+    {
+        const float3_ t = translation.empty() ? float3_{ 0, 0, 0 } : translation.at(time);
+        const float4_ q = rotation.empty() ? float4_{ 0, 0, 0, 0 } : rotation.at(time);
+        const float3_ s = scale.empty() ? float3_{ 0, 0, 0 } : scale.at(time);
+        float r[3][3];
+        rotation_rows(q, r);
+        const float tv[3] = { t.x, t.y, t.z }, sv[3] = { s.x, s.y, s.z };
+        auto R = [&](int k, int i) { return (k < 3 && i < 3) ? r[k][i] : ((k == 3 && i == 3) ? 1.0f : 0.0f); }; // [R 0; 0 1]
+        auto S = [&](int k, int i) { return k != i ? 0.0f : (k < 3 ? sv[k] : 1.0f); };                          // diag(s, 1)
+        for (int j = 0; j < 3; j++) {
+            float tr[4]; // row j of T * R; row j of T is (e_j, t_j)
+            for (int i = 0; i < 4; i++) {
+                float acc = (j == 0 ? 1.0f : 0.0f) * R(0, i);
+                acc = acc + (j == 1 ? 1.0f : 0.0f) * R(1, i);
+                acc = acc + (j == 2 ? 1.0f : 0.0f) * R(2, i);
+                acc = acc + tv[j] * R(3, i);
+                tr[i] = acc;
+            }
+            for (int i = 0; i < 4; i++) {
+                float acc = tr[0] * S(0, i);
+                acc = acc + tr[1] * S(1, i);
+                acc = acc + tr[2] * S(2, i);
+                acc = acc + tr[3] * S(3, i);
+                out[4 * j + i] = acc;
+            }
         }
-        int offset = first - 1;
-        if (key.size() - 1 <= (size_t)offset) return animation[key.size() - 1]; // sic: offset == -1 wraps and also lands here
-        float time_offset = time - key[offset];
-        float time_delta = key[offset + 1] - key[offset];
-        float delta = time_offset / time_delta;
-        return animation[offset] * (1.0f - delta) + animation[offset + 1] * (delta);
     }
-    float3_ translation(float time) const
-    {
-        return translation_data.key.size() ? animationInterpolate(translation_data.data, translation_data.key, time) : float3_{ 0, 0, 0 };
-    }
-    float4_ rotation(float time) const
-    {
-        return rotation_data.key.size() ? animationInterpolate(rotation_data.data, rotation_data.key, time) : float4_{ 0, 0, 0, 0 };
-    }
-    float3_ scale(float time) const
-    {
-        return scale_data.key.size() ? animationInterpolate(scale_data.data, scale_data.key, time) : float3_{ 0, 0, 0 };
-    }
-    Affine4x4 getAnimationAffine(float time) const // animation.h:81-94: T * R * S, no node hierarchy
-    {
-        return translateAffine(translation(time)) * rotateAffine(rotation(time)) * scaleAffine(scale(time));
-    }
-    Affine4x4 getRotateAnimationAffine(float time) const { return rotateAffine(rotation(time)); } // animation.h:96-103
+    // animation.h:96-103: the rotation alone (camera direction / up)
+    void rotation3x3(float time, float r[3][3]) const { rotation_rows(rotation.empty() ? float4_{ 0, 0, 0, 0 } : rotation.at(time), r); }
 };
 
 struct GeometryData { uint32_t index_offset, index_count; };   // scene.h:9-12
@@ -148,7 +128,7 @@ struct SceneData { // scene.h:19-36
     std::vector<hjr_texture> texture_views;
     std::vector<uint32_t> light_prim_ids;
     std::vector<float3_> light_prim_emission;
-    std::vector<Animation> animations;
+    std::vector<NodeMotion> animations; // one per glTF node (InstanceData.animation_id indexes it)
     std::vector<GeometryData> geometries;
     std::vector<InstanceData> instances;
     std::vector<uint32_t> prim_offset;

@@ -140,6 +140,13 @@ typedef struct hjr_stats {
              box_tests_shadow, tri_tests_shadow, shaded_hits, light_samples, nan_samples;
     float    last_kernel_ms;     /* HIP-event time of the last render kernel on its stream */
     uint32_t bvh_nodes, bvh_depth, n_triangles;
+    /* which megakernel layout the current frame data selects (csrc/hjr_device.hip::launch): 0 = BVH4 read from memory,
+     * 1 = BVH2 staged in LDS with 32-bit stack entries, 2 = BVH2 in LDS with 16-bit stack entries, 3 = BVH2 read from memory */
+    uint32_t lds_mode;
+    uint32_t stack_need;         /* worst-case traversal stack entries per lane of the current BVH */
+    uint32_t stack_lds_entries;  /* memory-path layouts: entries of a lane's stack kept in LDS; deeper ones overflow to HBM */
+    uint32_t _reserved;
+    uint64_t stack_overflow_pushes; /* HJR_FLAG_STATS launches: stack pushes that went to the HBM overflow (memory-path layouts) */
 } hjr_stats;
 
 typedef struct hjr_scene hjr_scene; /* owning, host side (SceneData + animations) */
@@ -206,6 +213,9 @@ int hjr_render_denoised(hjr_ctx*, const hjr_params*, int render_mode, float* out
 int hjr_denoise_device(hjr_ctx*, int render_mode, uint32_t in_w, uint32_t in_h, const void* d_color, const void* d_albedo,
                        const void* d_normal, void* d_out, uint32_t out_w, uint32_t out_h, void* hip_stream);
 int hjr_get_stats(hjr_ctx*, hjr_stats* out);
+/* Host-only self-test of the 16-bit traversal-stack encoding (csrc/hjr_traverse.hip.h): 0 when every child ref of a tree the
+ * builder admits to that layout survives encode + decode.  No reference counterpart (OptiX owns its traversal stack). */
+int hjr_selftest_stack16(void);
 
 /* ---------------- output stage (host) ---------------- */
 /* float4ConvertColor: toSRGB + quantizeUnsignedChar — renderer/renderer.h:73-101 */

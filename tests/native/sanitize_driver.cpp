@@ -35,6 +35,23 @@ int main(int argc, char** argv)
     hjr_camera cam;
     hjr::eval_camera(sc, opt, 1.0f / 24.0f, cam);
 
+    { // keyframe sampling rules of renderer/animation.h:42-67 on a hand-made track (keys 0.5, 1, 2 -> values 10, 20, 40)
+        hjr::Track<hjr::float3_> tr;
+        tr.push(0.5f, hjr::float3_{ 10, 0, 0 }); tr.push(1.0f, hjr::float3_{ 20, 0, 0 }); tr.push(2.0f, hjr::float3_{ 40, 0, 0 });
+        CHECK(tr.at(-1.0f).x == 10.0f);  // negative time: first key
+        CHECK(tr.at(0.25f).x == 40.0f);  // 0 <= time < first key: the reference's offset == -1 wraps and selects the LAST key (sic)
+        CHECK(tr.at(0.5f).x == 10.0f && tr.at(0.75f).x == 15.0f && tr.at(1.0f).x == 20.0f && tr.at(1.5f).x == 30.0f);
+        CHECK(tr.at(2.0f).x == 40.0f && tr.at(7.0f).x == 40.0f); // at / past the last key
+        hjr::Track<hjr::float3_> one;
+        one.push(3.0f, hjr::float3_{ 5, 6, 7 });
+        CHECK(one.at(0.0f).y == 6.0f && one.at(9.0f).z == 7.0f); // a single key is constant
+        hjr::NodeMotion nm; // identity TRS -> identity 3x4
+        nm.translation.push(0, hjr::float3_{ 0, 0, 0 }); nm.rotation.push(0, hjr::float4_{ 0, 0, 0, 1 }); nm.scale.push(0, hjr::float3_{ 1, 1, 1 });
+        float id[12];
+        nm.matrix3x4(0.0f, id);
+        for (int k = 0; k < 12; k++) CHECK(id[k] == ((k % 5 == 0) ? 1.0f : 0.0f));
+    }
+
     hjr_scene_view v;
     memset(&v, 0, sizeof(v));
     v.n_vertices = (uint32_t)sc.vertices.size(); v.n_triangles = (uint32_t)sc.indices.size() / 3; v.n_instances = ninst;

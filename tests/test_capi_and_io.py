@@ -31,8 +31,14 @@ def test_struct_layouts_match_header():
     assert C.sizeof(hjr.Material) == 80 and hjr.MATERIAL_DTYPE.itemsize == 80 and C.sizeof(hjr.Texture) == 24
     assert C.sizeof(hjr.Camera) == 52
     assert C.sizeof(hjr.Params) == 6 * 4 + 52 + 12 + 4 + 16
-    assert C.sizeof(hjr.Stats) == 10 * 8 + 16
+    assert C.sizeof(hjr.Stats) == 10 * 8 + 16 + 16 + 8
     assert C.sizeof(hjr.SceneView) == 8 * 4 + 13 * 8
+
+
+def test_stack16_encoding_roundtrips_every_ref_the_builder_can_emit():
+    """the 16-bit traversal-stack entry keeps a 2-bit triangle count; host/frame.cpp only admits trees with
+    leaves of <= 3 triangles, < 8192 triangles and < 32768 inner nodes to that layout, and every such ref must survive."""
+    assert hjr.lib().hjr_selftest_stack16() == 0
 
 
 def test_no_silent_fallback_without_gpu():

@@ -1,0 +1,125 @@
+"""Every shipped megakernel layout under a bit-exact parity test (VERDICT r01 task 1).
+
+hjr_device.hip::launch dispatches four layouts (hjr_stats.lds_mode): 0 = BVH4 read from memory, 1 = BVH2 staged in LDS with
+32-bit stack entries, 2 = BVH2 in LDS with 16-bit stack entries, 3 = BVH2 read from memory; the memory-path layouts keep the
+top of a lane's traversal stack in LDS and overflow into an HBM buffer.  The bundled scene only ever selects layout 1, so each
+other layout is forced here (the host-side knobs are read when the frame data is built / the kernel is launched) and checked,
+for NEE / Pathtrace / MIS with and without the albedo / normal AOVs, against the oracle's PORTABLE mode: same bar as
+test_gpu_parity.py.  The layout actually used and the overflow activity are asserted through hjr_stats.
+"""
+import contextlib
+import os
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+from scene_util import Cornell, StressScene, hjr
+from test_gpu_parity import assert_bitexact
+
+pytestmark = pytest.mark.gpu
+
+ALL_INTEGRATORS = (hjr.INTEGRATOR_NEE, hjr.INTEGRATOR_PT, hjr.INTEGRATOR_MIS)
+
+
+@contextlib.contextmanager
+def knobs(**kv):
+    old = {k: os.environ.get(k) for k in kv}
+    os.environ.update({k: str(v) for k, v in kv.items()})
+    try:
+        yield
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+_oracle_cache = {}
+
+
+def oracle_frame(scene, key, w, h, spp, integrator):
+    k = (key, w, h, spp, integrator)
+    if k not in _oracle_cache:
+        osc = ob.OracleScene(scene.arrays, ob.MATH_PORTABLE)
+        oc, oa, on, st = osc.render(scene.oracle_params(w, h, spp, integrator=integrator))
+        assert st["nan_samples"] == 0
+        _oracle_cache[k] = (oc, oa, on)
+    return _oracle_cache[k]
+
+
+def check_layout(scene, key, env, expect_mode, w=96, h=64, spp=4, integrators=ALL_INTEGRATORS, expect_overflow=False):
+    """Renders with the knobs set, asserts the layout, compares all AOVs (full variant) and the colour-only (lean) variant."""
+    with knobs(**env):
+        d = scene.device()  # host/frame.cpp reads the layout knobs here; the launch reads HJR_SHORT_STACK
+        try:
+            for integ in integrators:
+                oc, oa, on = oracle_frame(scene, key, w, h, spp, integ)
+                color, albedo, normal = d.render(scene.hjr_params(w, h, spp, integrator=integ))
+                st = d.stats()
+                assert st["lds_mode"] == expect_mode, (st["lds_mode"], expect_mode)
+                assert_bitexact(color, oc, "aov_color (AOVS on, integrator %d)" % integ)
+                assert_bitexact(albedo, oa, "aov_albedo")
+                assert_bitexact(normal, on, "aov_normal")
+                lean, _, _ = d.render(scene.hjr_params(w, h, spp, integrator=integ), want_aovs=False)
+                assert_bitexact(lean, oc, "aov_color (AOVS off, integrator %d)" % integ)
+                if expect_overflow:
+                    assert st["stack_need"] > st["stack_lds_entries"] > 0, st
+                    p = scene.hjr_params(w, h, spp, integrator=integ, flags=hjr.FLAG_STATS)
+                    counted, _, _ = d.render(p, want_aovs=False)
+                    assert_bitexact(counted, oc, "counting variant")
+                    assert d.stats()["stack_overflow_pushes"] > 0, "the overflow branch of LaneStack::put never ran"
+            return d.stats()
+        finally:
+            d.close()
+
+
+@pytest.fixture(scope="module")
+def cornell():
+    return Cornell()
+
+
+def test_default_layout_is_lds32(cornell):
+    st = check_layout(cornell, "cornell", {}, expect_mode=1)
+    assert st["stack_need"] == st["bvh_depth"] + 2
+
+
+def test_lds_bvh2_with_16bit_stack_forced_on_cornell(cornell):
+    """lds_mode 2 (STACK16): the 16-bit entries are normally chosen only when 32-bit ones do not fit; HJR_LDS_STACK16=1 prefers them."""
+    check_layout(cornell, "cornell", {"HJR_LDS_STACK16": 1}, expect_mode=2)
+
+
+def test_lds_bvh2_with_16bit_stack_chosen_by_the_builder(tmp_path):
+    """A generated scene inside the window (~1.2-1.5 k triangles) where the builder itself selects the 16-bit stack layout."""
+    s = StressScene(tmp_path, spheres=6, segments=16)
+    assert s.scene.view.n_triangles == 12 + 6 * 224
+    check_layout(s, "ss6x16", {}, expect_mode=2, w=80, h=45, spp=3)
+
+
+def test_bvh4_from_memory_on_cornell(cornell):
+    """lds_mode 0 on the bundled scene (HJR_LDS_BVH=0), whole stack in LDS (14 entries < 16)."""
+    st = check_layout(cornell, "cornell", {"HJR_LDS_BVH": 0}, expect_mode=0)
+    assert st["stack_lds_entries"] == min(st["stack_need"], 16)
+
+
+def test_bvh2_from_memory_on_cornell(cornell):
+    """lds_mode 3: BVH2 nodes read from memory (HJR_BVH_WIDTH=2 with the LDS staging off)."""
+    check_layout(cornell, "cornell", {"HJR_LDS_BVH": 0, "HJR_BVH_WIDTH": 2}, expect_mode=3)
+
+
+@pytest.mark.parametrize("width,mode", [(4, 0), (2, 3)])
+def test_stack_overflow_path(cornell, width, mode):
+    """Two LDS entries per lane: every deeper push goes through the HBM overflow buffer ([level][lane]) and comes back."""
+    check_layout(cornell, "cornell", {"HJR_LDS_BVH": 0, "HJR_BVH_WIDTH": width, "HJR_SHORT_STACK": 2}, expect_mode=mode,
+                 expect_overflow=True)
+
+
+def test_memory_layouts_on_a_deep_scene(tmp_path):
+    """~60 k triangles (BVH4 stack need > 16): default short stack of 16 with real overflow, and the BVH2-from-memory layout."""
+    s = StressScene(tmp_path, spheres=8, segments=88)
+    st = check_layout(s, "ss8x88", {}, expect_mode=0, w=64, h=36, spp=2, integrators=(hjr.INTEGRATOR_NEE,))
+    assert st["stack_need"] > 16 and st["stack_lds_entries"] == 16
+    check_layout(s, "ss8x88", {"HJR_BVH_WIDTH": 2}, expect_mode=3, w=64, h=36, spp=2, integrators=(hjr.INTEGRATOR_NEE, hjr.INTEGRATOR_MIS))
+    check_layout(s, "ss8x88", {"HJR_SHORT_STACK": 3}, expect_mode=0, w=64, h=36, spp=2, integrators=(hjr.INTEGRATOR_NEE,),
+                 expect_overflow=True)

@@ -43,7 +43,7 @@ int main(int argc, char** argv)
         unsigned long long h = 1469598103934665603ull; // FNV-1a over the emitted arrays: the build must not depend on threads
         auto mix = [&](const void* p, size_t n) { const unsigned char* b = (const unsigned char*)p; for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; } };
         mix(fd.nodes.data(), fd.nodes.size() * 4); mix(fd.tri_geom.data(), fd.tri_geom.size() * 4); mix(fd.tri_shade.data(), fd.tri_shade.size() * 4);
-        printf("build_frame: %.1f ms  (%u tris, %u nodes, width %u, depth %u, stack %u)  hash %016llx\n", ms, fd.n_tris, fd.n_nodes, fd.width, fd.depth, fd.stack_need, h);
+        printf("build_frame: %.1f ms  (%u tris, %u nodes, width %u, depth %u, stack %u, lds_mode %d)  hash %016llx\n", ms, fd.n_tris, fd.n_nodes, fd.width, fd.depth, fd.stack_need, fd.lds_mode, h);
     }
     return 0;
 }

@@ -10,8 +10,16 @@ Scene, BVH and all buffers are resident in HBM before the timed region.
     N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
                 bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0 (contract in the task statement), plus
-  "roofline":     algorithmic HBM bytes per launch / measured kernel time (HIP events on the kernel's stream) vs 8 TB/s
+Prints ONE JSON line on rank 0 (contract in the task statement).  `value` is the rate of the launch the reference's raygen
+performs (colour + albedo + normal AOVs, renderer/renderer.h:1222-1224); `color_only` carries the rate of the lean colour-only
+instantiation next to it.  Plus
+  "roofline":     the bound is chosen per launch from hardware counters collected IN THIS RUN (rocprofv3 --pmc passes over
+                  tools/kbench, the same library and workload, started before this process touches the GPU):
+                    * scene resident in LDS / L2 (measured HBM rate far below peak): bound "valu" — useful fp32 VALU lane
+                      operations (wave instructions x average active lanes, x 2 FLOP) per second against the 157.3 TFLOP/s
+                      vector peak of MI355X_MICROARCH.md; <= 1 by construction;
+                    * otherwise bound "hbm" with the COUNTER bytes (FETCH_SIZE x 2 + WRITE_SIZE) against 8 TB/s.
+                  SURVEY.md section 8d's algorithmic-bytes figure stays as a side field (it counts reads that LDS serves).
   "cpu_baseline": the CPU oracle (a from-scratch port; the reference has no CPU path) timed on the host cores
 """
 import argparse
@@ -37,6 +45,58 @@ def algorithmic_bytes_per_sample(st, spp):
     return b + 52.0 / spp
 
 
+VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 (vector) = 256 CUs x 4 SIMDs x 32 lanes x 2 FLOP x 2.4 GHz
+PMC_PASSES = [  # separate passes: SQ has 8 slots, FETCH_SIZE / WRITE_SIZE do not fit one TCC pass (MI355X_MICROARCH.md, PMC slots)
+    ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "GRBM_GUI_ACTIVE"],
+    ["FETCH_SIZE"],
+    ["WRITE_SIZE"],
+]
+
+
+def collect_pmc(kbench_args, env=None, timeout=150):
+    """Runs tools/kbench (one warm-up + one measured frame of the bench workload through the same libhenjou_hip.so) under
+    `rocprofv3 --pmc`, one pass per counter group, and returns {counter: value per FRAME summed over the product's kernels}.
+    The program itself follows `--` (no shell / env / launcher hop).  Raises on any failure: the caller decides what to report."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    kb = os.path.join(ROOT, "tools", "kbench")
+    rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(kb):
+        raise RuntimeError("tools/kbench is not built (python -c 'import __graft_entry__ as g; g.build()')")
+    if not os.path.exists(rp):
+        raise RuntimeError("rocprofv3 not found")
+    out = {}
+    frames = 2  # kbench --reps 1 renders the frame twice (warm-up + 1)
+    e = dict(os.environ)
+    e.update(env or {})
+    e["TMPDIR"] = "/tmp"
+    for counters in PMC_PASSES:
+        d = tempfile.mkdtemp(prefix="hjr_pmc_", dir="/tmp")
+        try:
+            cmd = [rp, "--pmc"] + counters + ["--output-format", "csv", "-d", d, "--", kb] + kbench_args
+            r = subprocess.run(cmd, cwd=os.path.join(ROOT, "henjou-renderer_amd", "assets"), env=e, capture_output=True, text=True, timeout=timeout)
+            if r.returncode != 0:
+                raise RuntimeError("rocprofv3 pass %s failed (rc %d): %s" % (counters, r.returncode, (r.stderr or r.stdout)[-400:]))
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if not files:
+                raise RuntimeError("rocprofv3 pass %s wrote no counter_collection.csv" % counters)
+            acc = {}
+            for f in files:
+                for row in csv.DictReader(open(f)):
+                    if "hjr_" in row["Kernel_Name"]:
+                        acc[row["Counter_Name"]] = acc.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+            for c in counters:
+                if c not in acc:
+                    raise RuntimeError("counter %s missing from the rocprofv3 output" % c)
+                out[c] = acc[c] / frames
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -51,10 +111,38 @@ def main():
     ap.add_argument("--stress-spheres", type=int, default=64)
     ap.add_argument("--stress-segments", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-spp", type=int, default=64, help="spp of the bounded CPU-baseline sample")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 counter passes (roofline.frac / traffic become null)")
+    ap.add_argument("--cpu-spp", type=int, default=1024, help="spp of the bounded CPU-baseline sample (the metric's RMSE is quoted at 1024 spp)")
     ap.add_argument("--cpu-threads", type=int, default=int(os.environ.get("HJR_CPU_THREADS", "16")),
                     help="oracle threads for the CPU baseline (a 1-GPU box's CPU share is 16 cores)")
     args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    # ---- hardware counters of this workload, collected in child processes BEFORE this process initialises the GPU
+    pmc, pmc_full, pmc_error = None, None, None
+    config_json = {"cornell": "render_option_c2.json", "thinfilm": "render_option_c3.json", "ior15": "render_option_c4.json"}.get(args.scene)
+    if rank == 0 and not args.no_pmc and "HJR_BENCH_DEVICE" not in os.environ:
+        try:
+            kcfg = config_json
+            if args.scene == "stress":
+                import subprocess
+                import tempfile
+                sdir0 = os.path.join(tempfile.gettempdir(), "hjr_stress_%d_%d_r%d" % (args.stress_spheres, args.stress_segments, rank))
+                subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_stress_scene.py"), sdir0, "--spheres",
+                                       str(args.stress_spheres), "--segments", str(args.stress_segments)], stdout=subprocess.DEVNULL)
+                kcfg = os.path.join(sdir0, "render_option_stress.json")
+            lib_path = os.environ.get("HJR_LIB") or os.path.join(ROOT, "henjou-renderer_amd", "libhenjou_hip.so")
+            kargs = [lib_path, kcfg, "--width", str(args.width), "--height", str(args.height), "--spp", str(args.spp), "--reps", "1",
+                     "--integrator", str({"NEE": 0, "Pathtrace": 1, "MIS": 2}[args.integrator]), "--rank", "0", "--world", str(world)]
+            penv = {"HIP_VISIBLE_DEVICES": str(local_rank), "ROCR_VISIBLE_DEVICES": ""} if world > 1 else {}
+            penv = {k: v for k, v in penv.items() if v}
+            pmc_full = collect_pmc(kargs + ["--aovs"], env=penv)
+            pmc = collect_pmc(kargs, env=penv)
+        except Exception as ex:  # reported on the line; never silently replaced by a committed file
+            pmc_error = "%s: %s" % (type(ex).__name__, ex)
 
     import numpy as np
     import torch
@@ -62,9 +150,6 @@ def main():
     import __graft_entry__ as entry
     hjr = entry.load_package()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
@@ -90,7 +175,7 @@ def main():
     os.chdir(hjr.ASSETS)
     try:
         r = hjr.Renderer(local_rank)
-        config = {"cornell": "render_option_c2.json", "thinfilm": "render_option_c3.json", "ior15": "render_option_c4.json"}.get(args.scene)
+        config = config_json
         if args.scene == "stress":
             import subprocess
             import tempfile
@@ -112,9 +197,15 @@ def main():
     r.device.set_transforms(m, inv)
 
     fb = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+    fb_albedo = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+    fb_normal = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
 
-    def step():
+    def step_full():  # what the reference's launch produces: aov_color + aov_albedo + aov_normal (renderer.h:1222-1224)
+        r.device.render_device(params, fb.data_ptr(), fb_albedo.data_ptr(), fb_normal.data_ptr(), stream)
+        hjr.exchange_framebuffer(fb, dst=0)
+
+    def step_color():  # the lean colour-only instantiation (only aov_color reaches the PNG in Default mode)
         r.device.render_device(params, fb.data_ptr(), None, None, stream)
         hjr.exchange_framebuffer(fb, dst=0)
 
@@ -123,20 +214,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    kernel_ms = []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        kernel_ms.append(r.device.stats()["last_kernel_ms"])  # HIP events recorded on the launch stream around the kernel
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed(step):
+        for _ in range(args.warmup):
+            step()
+        fence()
+        ms = []
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+            ms.append(r.device.stats()["last_kernel_ms"])  # HIP events recorded on the launch stream around the kernel(s)
+        fence()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, ms
+
+    elapsed_color, kernel_ms_color = timed(step_color)
+    elapsed, kernel_ms = timed(step_full)  # the headline: EXACTLY args.steps steps between the fences
 
     total_samples = float(W) * H * SPP * args.steps
     value = total_samples / elapsed / 1e6
@@ -148,6 +244,10 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "aovs": "color+albedo+normal (the reference raygen's outputs)",
+        "color_only": {"value": round(total_samples / elapsed_color / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(elapsed_color / args.steps * 1e3, 3),
+                       "kernel_ms_avg": round(sum(kernel_ms_color) / len(kernel_ms_color), 3),
+                       "note": "same workload, aov_color only (lean kernel instantiation; Default mode writes only this AOV to the PNG)"},
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
@@ -170,42 +270,59 @@ def main():
         bps = algorithmic_bytes_per_sample(st, SPP)
         samples_per_launch = float(W) * H * SPP / world
         avg_ms = sum(kernel_ms) / len(kernel_ms)
-        achieved = bps * samples_per_launch / (avg_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get("%s_%dx%dx%d_%s_n%d" % (args.scene, W, H, SPP, args.integrator, world))
-            except Exception:
-                traffic = None
-        # next to the algorithmic-bytes fraction, the measured HBM rate and the VALU issue load (the binding limit of
-        # the LDS-resident scene) from the committed rocprofv3 PMC passes of this exact workload, scaled by the live kernel time
-        side = None
-        try:
-            prof = json.load(open(tpath))
-            key = "%s_%dx%dx%d_%s_n%d" % (args.scene, W, H, SPP, args.integrator, world)
-            if traffic is not None and (key + "_valu_insts") in prof:
-                valu = float(prof[key + "_valu_insts"])
-                clk = float(prof[key + "_gui_active_cycles_x8"]) / 8.0  # shader-clock cycles of the profiled launch
-                side = {"hbm_measured_GBps": round(traffic / (avg_ms * 1e-3) / 1e9, 2),
-                        "hbm_measured_frac": round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
-                        "valu_wave_insts_per_launch": valu,
-                        "simd_cycles_per_valu_inst": round(clk * 1024.0 / valu, 3),
-                        "note": "256 CUs x 4 SIMDs; measured issue cost 2.6 (v_xor) .. 3.9 (v_fma_f32) .. 8.3 (v_rcp/v_sqrt) cycles per wave-instruction (tools/ubench/valu_rate.hip): VALU issue is the binding limit, HBM is idle"}
-        except Exception:
-            side = None
-        out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                           "kernel": "hjr_render_kernel<%s>" % args.integrator, "kernel_ms_avg": round(avg_ms, 3),
-                           "algorithmic_bytes_per_sample": round(bps, 1),
-                           "per_sample": {k: round(st[k] / max(st["samples"], 1), 3) for k in
-                                          ("closest_rays", "shadow_rays", "box_tests_closest", "tri_tests_closest",
-                                           "box_tests_shadow", "tri_tests_shadow", "shaded_hits", "light_samples")},
-                           "kernel_Msamples_per_s": round(samples_per_launch / (avg_ms * 1e-3) / 1e6, 3)}
-        if side:
-            out["roofline"]["side_by_side"] = side
+        avg_ms_color = sum(kernel_ms_color) / len(kernel_ms_color)
+        algorithmic_gbs = bps * samples_per_launch / (avg_ms * 1e-3) / 1e9
 
-        # ---- CPU baseline: the oracle (kind "port": the reference has no CPU path), bounded sample
+        def counters_view(c, ms):
+            """Roofline figures from one set of per-launch counters and the LIVE kernel time of that variant."""
+            t = ms * 1e-3
+            hbm_bytes = c["FETCH_SIZE"] * 1024.0 * 2.0 + c["WRITE_SIZE"] * 1024.0  # KiB counters; gfx950: FETCH_SIZE reports half of wide reads
+            lanes = c["SQ_THREAD_CYCLES_VALU"] / max(c["SQ_ACTIVE_INST_VALU"], 1.0)  # average active lanes per VALU wave-instruction
+            lane_ops = c["SQ_INSTS_VALU"] * lanes
+            clk = c["GRBM_GUI_ACTIVE"] / 8.0  # shader cycles of the profiled launch (sum over the 8 XCDs / 8)
+            return {"hbm_bytes": hbm_bytes, "hbm_GBps": hbm_bytes / t / 1e9, "valu_tflops": lane_ops * 2.0 / t / 1e12,
+                    "active_lane_frac": lanes / 64.0, "valu_wave_insts": c["SQ_INSTS_VALU"],
+                    "simd_cycles_per_valu_inst": clk * 1024.0 / max(c["SQ_INSTS_VALU"], 1.0),
+                    "sq_active_inst_any_frac": c["SQ_ACTIVE_INST_ANY"] / max(c["SQ_WAVE_CYCLES"], 1.0),
+                    "sq_wait_inst_any_frac": c["SQ_WAIT_INST_ANY"] / max(c["SQ_WAVE_CYCLES"], 1.0)}
+
+        roof = {"kernel": "hjr render kernels (%s, 3 AOVs)" % args.integrator, "kernel_ms_avg": round(avg_ms, 3),
+                "kernel_Msamples_per_s": round(samples_per_launch / (avg_ms * 1e-3) / 1e6, 3),
+                "algorithmic": {"bytes_per_sample": round(bps, 1), "GBps": round(algorithmic_gbs, 2),
+                                "note": "SURVEY 8d per-visit byte model x measured rate: counts node / triangle reads that LDS and L2 serve, so it is not a roofline",
+                                "per_sample": {k: round(st[k] / max(st["samples"], 1), 3) for k in
+                                               ("closest_rays", "shadow_rays", "box_tests_closest", "tri_tests_closest",
+                                                "box_tests_shadow", "tri_tests_shadow", "shaded_hits", "light_samples")}}}
+        if pmc_full is not None:
+            v = counters_view(pmc_full, avg_ms)
+            hbm_frac = v["hbm_GBps"] / HBM_PEAK_GBS
+            if hbm_frac < 0.05:  # the scene is served by LDS / L2: the vector ALUs are the roof
+                roof.update({"bound": "valu", "achieved": round(v["valu_tflops"], 3), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": round(v["valu_tflops"] / VALU_PEAK_TFLOPS, 5),
+                             "definition": "SQ_INSTS_VALU x (SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU) active lanes x 2 FLOP per launch / live kernel time, vs the fp32 vector peak"})
+            else:
+                roof.update({"bound": "hbm", "achieved": round(v["hbm_GBps"], 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_frac, 5),
+                             "definition": "(FETCH_SIZE x 2 + WRITE_SIZE) counter bytes per launch / live kernel time, vs 8 TB/s (Infinity-Cache hits are counted by FETCH_SIZE)"})
+            roof["traffic"] = int(v["hbm_bytes"])
+            roof["counters"] = {"source": "rocprofv3 --pmc passes of tools/kbench inside this run (same library, workload, GPU)",
+                                "active_lane_frac": round(v["active_lane_frac"], 4), "valu_wave_insts_per_launch": v["valu_wave_insts"],
+                                "simd_cycles_per_valu_inst": round(v["simd_cycles_per_valu_inst"], 3),
+                                "hbm_GBps": round(v["hbm_GBps"], 2), "hbm_frac": round(hbm_frac, 6), "valu_TFLOPs": round(v["valu_tflops"], 3),
+                                "valu_frac": round(v["valu_tflops"] / VALU_PEAK_TFLOPS, 5),
+                                "sq_active_inst_any_frac": round(v["sq_active_inst_any_frac"], 4), "sq_wait_inst_any_frac": round(v["sq_wait_inst_any_frac"], 4)}
+            if pmc is not None:
+                vc = counters_view(pmc, avg_ms_color)
+                roof["counters"]["color_only"] = {"active_lane_frac": round(vc["active_lane_frac"], 4), "valu_TFLOPs": round(vc["valu_tflops"], 3),
+                                                  "valu_frac": round(vc["valu_tflops"] / VALU_PEAK_TFLOPS, 5), "hbm_bytes": int(vc["hbm_bytes"])}
+        else:
+            roof.update({"bound": "valu", "achieved": None, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None,
+                         "counters": {"source": "not collected", "reason": pmc_error or ("--no-pmc" if args.no_pmc else "rank / rehearsal run")}})
+        out["roofline"] = roof
+
+        # ---- CPU baseline: the oracle (kind "port": the reference has no CPU path, SURVEY.md §0 F3) on a bounded sample of the same
+        #      workload: a centred window of the SAME frame (same camera, same resolution) at the metric's 1024 spp.  The same
+        #      render doubles as the accuracy check BASELINE.json's metric names: per-pixel RMSE of the product's frame against the
+        #      reference arithmetic with glibc transcendentals (LIBM mode) at identical sample streams.
         if world == 1 and not args.no_cpu_baseline:
             import oracle_binding as ob
             cores = os.cpu_count() or 1
@@ -215,17 +332,34 @@ def main():
                 pass
             cores = max(1, min(cores, args.cpu_threads))
             arrays = r.scene.arrays(t_frame)
+            if r.lut is not None:
+                arrays["lut_rgba"] = r.lut
             osc = ob.OracleScene(arrays, ob.MATH_LIBM)
-            cspp = max(1, min(args.cpu_spp, SPP))
+            cspp = args.cpu_spp
+            # window sized for ~130 Msamples of CPU work (10-30 s on 16 cores)
+            ww = max(8, min(W, int(round((130e6 / cspp * W / H) ** 0.5)) // 8 * 8))
+            wh = max(8, min(H, int(round(ww * H / W)) // 8 * 8))
+            x0, y0 = (W - ww) // 2 // 8 * 8, (H - wh) // 2 // 8 * 8
+            rect = (x0, y0, x0 + ww, y0 + wh)
             op = ob.make_params(W, H, cspp, params.camera.as_dict(), frame=params.frame, seed=params.seed, integrator=integ,
-                                sky=tuple(params.sky), ibl_intensity=params.ibl_intensity)
+                                sky=tuple(params.sky), ibl_intensity=params.ibl_intensity, rect=rect)
             tc = time.perf_counter()
-            osc.render(op, nthreads=cores, want_aovs=False)
+            ocol, _, _, _ = osc.render(op, nthreads=cores, want_aovs=False)
             dtc = time.perf_counter() - tc
-            out["cpu_baseline"] = {"value": round(W * H * cspp / dtc / 1e6, 4), "unit": "Msamples/s", "cores": cores,
+            gp = hjr.make_params(W, H, cspp, params.camera, frame=params.frame, seed=params.seed, integrator=integ,
+                                 sky=tuple(params.sky), ibl_intensity=params.ibl_intensity)
+            r.device.render_device(gp, fb.data_ptr(), None, None, stream)
+            torch.cuda.synchronize()
+            g = fb[y0:y0 + wh, x0:x0 + ww, :3].cpu().numpy().astype(np.float64)
+            o = ocol[y0:y0 + wh, x0:x0 + ww, :3].astype(np.float64)
+            rmse = float(np.sqrt(np.mean((g - o) ** 2)))
+            out["cpu_baseline"] = {"value": round(ww * wh * cspp / dtc / 1e6, 4), "unit": "Msamples/s", "cores": cores,
                                    "kind": "port",
-                                   "sample": "same frame (%dx%d), first %d of %d spp = %.2f Msamples, oracle/hjr_oracle.c in LIBM mode, "
-                                             "%d pthreads over image rows, %.1f s" % (W, H, cspp, SPP, W * H * cspp / 1e6, cores, dtc)}
+                                   "sample": "window x %d..%d, y %d..%d of the same %dx%d frame at %d spp = %.2f Msamples, oracle/hjr_oracle.c in LIBM mode, "
+                                             "%d pthreads, %.1f s" % (x0, x0 + ww, y0, y0 + wh, W, H, cspp, ww * wh * cspp / 1e6, cores, dtc),
+                                   "rmse_gpu_vs_cpu": {"value": rmse, "spp": cspp, "pixels": ww * wh, "tolerance": 1e-3,
+                                                       "note": "per-pixel RMSE (linear RGB) of the HIP frame against the CPU restatement with glibc transcendentals, "
+                                                               "identical sample streams; no OptiX render can exist here (SURVEY.md section 0)"}}
         print(json.dumps(out))
         sys.stdout.flush()
     if world > 1:

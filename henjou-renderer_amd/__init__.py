@@ -464,8 +464,10 @@ class Renderer:
         self.device = Device(self.device_ordinal)
         self.device.upload_scene(self.scene.view)
         lut_path = self.render_option.LUT_path.decode()
+        self.lut = None
         if lut_path and os.path.exists(lut_path):
-            self.device.set_lut(load_png(lut_path))
+            self.lut = load_png(lut_path)
+            self.device.set_lut(self.lut)
         ibl = self.render_option.IBL_path.decode()
         if self.render_option.use_IBL and ibl and os.path.exists(ibl):  # setSky (renderer.h:802-851)
             self.device.set_sky(load_hdr(ibl))

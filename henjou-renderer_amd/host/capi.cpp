@@ -180,8 +180,9 @@ extern "C" int hjr_write_pfm(const char* path, const float* rgba, uint32_t w, ui
     return HJR_OK;
 }
 
-// Renderer::initializeAndRender — renderer/renderer.h:1053-1317.  Only Render_mode "Default" is in scope: the denoise
-// modes need the OptiX AI denoiser (renderer/denoiser.h), which in Default mode is an identity pass (blendFactor 1).
+// Renderer::initializeAndRender — renderer/renderer.h:1053-1317.  Render_mode "Default" is the pass-through of the reference
+// (its denoiser runs with blendFactor 1); "Denoise" / "DenoiseUpScale2X" keep the reference's data flow with the HIP a-trous
+// filter in place of the closed OptiX network (csrc/hjr_denoise.hip.h).
 extern "C" int hjr_render_file(const char* render_option_json, int device)
 {
     if (!render_option_json) { set_error("hjr_render_file: null path"); return HJR_ERR_ARG; }

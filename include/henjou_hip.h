@@ -30,8 +30,16 @@ extern "C" {
 enum { HJR_INTEGRATOR_NEE = 0, HJR_INTEGRATOR_PT = 1, HJR_INTEGRATOR_MIS = 2 }; /* kernel/rt.h:162,85,284 */
 enum { HJR_MODE_DEFAULT = 0, HJR_MODE_DENOISE = 1, HJR_MODE_DENOISE_UPSCALE2X = 2, HJR_MODE_DEBUG = 3 }; /* renderer/render_option.h:38-43 */
 
-/* Mirror of HitGroupData (renderer/renderer.h:659-687) as filled from Material (renderer/material.h:10-63).
- * Texture slots other than base colour are carried for the loader's sake; the kernel ignores them. */
+/* Material record of the hot path: the fields of HitGroupData (renderer/renderer.h:659-687, filled from Material,
+ * renderer/material.h:10-63) that the kernel-side code under include/kernel/ reads, in a 16-byte-aligned 80-byte layout.
+ * It is NOT field-for-field HitGroupData; a binding fills it per material like this (INTEGRATION.md has the code):
+ *   kept as is : basecolor, metallic, roughness, sheen, clearcoat, ior, transmission, emmision -> emission, is_light,
+ *                ideal_specular, is_thinfilm, basecolor_tex, normal_tex, emmision_tex -> emission_tex
+ *   merged     : metallic_tex + roughness_tex -> metallic_roughness_tex (the glTF loader always binds the same image to both,
+ *                gltfloader.h:1144-1156; G = roughness, B = metallic)
+ *   dropped    : specular (float3; no kernel header reads it), clearcoat_tex, bump_tex (bound by the host, read only by the
+ *                missing closest-hit program; the clearcoat factor itself is kept)
+ * normal_tex / emission_tex are carried for the loader's sake and not sampled (no tangent frame on this path). */
 typedef struct hjr_material {
     float basecolor[3];
     float metallic;

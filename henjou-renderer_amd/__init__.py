@@ -19,7 +19,7 @@ ASSETS = os.path.join(PKG_DIR, "assets")
 
 INTEGRATOR_NEE, INTEGRATOR_PT, INTEGRATOR_MIS = 0, 1, 2
 MODE_DEFAULT, MODE_DENOISE, MODE_DENOISE_UPSCALE2X, MODE_DEBUG = 0, 1, 2, 3  # render_option.h:38-43
-FLAG_STATS, FLAG_ZERO_UNOWNED = 1, 2
+FLAG_STATS, FLAG_ZERO_UNOWNED, FLAG_PACKED = 1, 2, 4
 
 
 class HjrError(RuntimeError):
@@ -92,7 +92,7 @@ class Stats(C.Structure):
                                            "shaded_hits", "light_samples", "nan_samples")] + \
                [("last_kernel_ms", C.c_float), ("bvh_nodes", C.c_uint32), ("bvh_depth", C.c_uint32),
                 ("n_triangles", C.c_uint32), ("lds_mode", C.c_uint32), ("stack_need", C.c_uint32),
-                ("stack_lds_entries", C.c_uint32), ("_reserved", C.c_uint32), ("stack_overflow_pushes", C.c_uint64)]
+                ("stack_lds_entries", C.c_uint32), ("pipeline", C.c_uint32), ("stack_overflow_pushes", C.c_uint64)]
 
     def as_dict(self):
         return {n: (float(getattr(self, n)) if n == "last_kernel_ms" else int(getattr(self, n)))
@@ -144,10 +144,17 @@ def lib():
             "hjr_denoise": [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32],
             "hjr_denoise_device": [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p],
             "hjr_render_denoised": [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_uint32],
+            "hjr_pack_tiles": [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p],
+            "hjr_unpack_tiles": [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p],
+            "hjr_pack_tiles_device": [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p],
+            "hjr_unpack_tiles_device": [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p],
+            "hjr_selftest_stack16": [],
         }.items():
             fn = getattr(L, name)
             fn.restype = C.c_int
             fn.argtypes = args
+        L.hjr_owned_tiles.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+        L.hjr_owned_tiles.restype = C.c_uint32
         L.hjr_scene_free.argtypes = [C.c_void_p]
         L.hjr_scene_free.restype = None
         L.hjr_destroy.argtypes = [C.c_void_p]
@@ -431,13 +438,66 @@ def owned_tile_mask(width, height, rank, world_size, tile=8):
 
 
 def exchange_framebuffer(fb, dst=0):
-    """The one data-path collective of a multi-GPU frame: every rank holds its own 8x8 tiles and zeros
-    elsewhere; a SUM reduce onto `dst` assembles the frame.  Adding zeros is exact in IEEE arithmetic, so the result is
-    bit-identical to the 1-GPU image.  `fb` is a torch tensor (CUDA -> RCCL over xGMI; CPU -> gloo in the tests)."""
+    """Full-frame form of the multi-GPU exchange (what north_star names): every rank holds its own 8x8 tiles and zeros
+    elsewhere (HJR_FLAG_ZERO_UNOWNED); a SUM reduce onto `dst` assembles the frame.  Adding zeros is exact in IEEE arithmetic,
+    so the result is bit-identical to the 1-GPU image.  `fb` is a torch tensor (CUDA -> RCCL over xGMI; CPU -> gloo in the
+    tests).  gather_tiles below moves 1 / world of these bytes and is what bench.py and henjou_cli use."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.reduce(fb, dst=dst, op=dist.ReduceOp.SUM)
     return fb
+
+
+def owned_tiles(width, height, rank, world_size):
+    return int(lib().hjr_owned_tiles(width, height, rank, world_size))
+
+
+def pack_tiles(frame, rank, world_size):
+    """Host form of the packed layout: [owned tile][64] float4 of `rank` from a row-major float4 frame (hjr_pack_tiles)."""
+    frame = np.ascontiguousarray(frame, dtype=np.float32)
+    h, w = frame.shape[:2]
+    out = np.zeros((owned_tiles(w, h, rank, world_size), 64, 4), dtype=np.float32)
+    _check(lib().hjr_pack_tiles(frame.ctypes.data, w, h, rank, world_size, out.ctypes.data), "hjr_pack_tiles")
+    return out
+
+
+def unpack_tiles(packed, frame, rank, world_size):
+    """Scatters one rank's packed tiles into `frame` (row-major float4, modified in place; hjr_unpack_tiles)."""
+    packed = np.ascontiguousarray(packed, dtype=np.float32)
+    h, w = frame.shape[:2]
+    assert frame.dtype == np.float32 and frame.flags["C_CONTIGUOUS"]
+    _check(lib().hjr_unpack_tiles(packed.ctypes.data, w, h, rank, world_size, frame.ctypes.data), "hjr_unpack_tiles")
+    return frame
+
+
+def gather_tiles(packed, width, height, device=None, dst=0, frame=None):
+    """The multi-GPU exchange sized by ownership: every rank contributes its packed tiles
+    ([max owned tiles][64][4] float32 torch tensor, the same shape on every rank: ranks owning one tile fewer pad), rank `dst`
+    receives the world_size blocks (RCCL gather = point-to-point sends over xGMI, all peers in parallel) and scatters each into
+    the row-major frame: on a CUDA tensor with hjr_unpack_tiles_device (`device` = the rank's hjr Device), on a CPU tensor
+    (gloo, tests) with hjr_unpack_tiles.  Returns the assembled frame on `dst`, None elsewhere."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    blocks = None
+    if world > 1:
+        if rank == dst:
+            blocks = [torch.empty_like(packed) for _ in range(world)]
+        dist.gather(packed, gather_list=blocks, dst=dst)
+    else:
+        blocks = [packed]
+    if rank != dst:
+        return None
+    if frame is None:
+        frame = torch.zeros((height, width, 4), dtype=torch.float32, device=packed.device)
+    for r, blk in enumerate(blocks):
+        if blk.is_cuda:
+            _check(lib().hjr_unpack_tiles_device(device._h, C.c_void_p(blk.data_ptr()), width, height, r, world, C.c_void_p(frame.data_ptr()),
+                                                 C.c_void_p(torch.cuda.current_stream().cuda_stream)), "hjr_unpack_tiles_device")
+        else:
+            unpack_tiles(blk.numpy(), frame.numpy(), r, world)
+    return frame
 
 
 class Renderer:

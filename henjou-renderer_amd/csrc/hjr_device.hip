@@ -15,6 +15,7 @@
 #include "../../include/henjou_hip.h"
 #include "../host/frame.hpp"
 #include "hjr_kernel.hip.h"
+#include "hjr_wavefront.hip.h"
 #include "hjr_denoise.hip.h"
 
 namespace hjr {
@@ -62,6 +63,7 @@ struct hjr_ctx {
     DevBuf d_color, d_albedo, d_normal; // staging for hjr_render (host buffers)
     DevBuf d_part_color, d_part_albedo, d_part_normal; // chunk sums [n_chunks][H][W] float4
     DevBuf d_spill; // overflow of the short traversal stacks (memory-path kernels)
+    DevBuf d_wf_ctx; // context planes of the wavefront kernel
     DevBuf d_tiles; // [tile_order | tile_class] of the cost-ordered tile list
     DevBuf d_tile_cost; // measured per-tile cost of the previous frame
     uint64_t cost_tag = 0; // (width, height, spp, rank, world, integrator) the costs belong to; 0 = none
@@ -118,7 +120,7 @@ extern "C" void hjr_destroy(hjr_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    for (DevBuf* b : { &c->d_nodes, &c->d_tri_geom, &c->d_tri_shade, &c->d_tri_inst, &c->d_materials, &c->d_lights, &c->d_lut, &c->d_spill, &c->d_tiles, &c->d_tile_cost, &c->d_dn_a, &c->d_dn_b, &c->d_dn_out,
+    for (DevBuf* b : { &c->d_nodes, &c->d_tri_geom, &c->d_tri_shade, &c->d_tri_inst, &c->d_materials, &c->d_lights, &c->d_lut, &c->d_spill, &c->d_wf_ctx, &c->d_tiles, &c->d_tile_cost, &c->d_dn_a, &c->d_dn_b, &c->d_dn_out,
                        &c->d_texels, &c->d_tex_desc, &c->d_srgb_lut, &c->d_sky, &c->d_work, &c->d_color, &c->d_albedo, &c->d_normal, &c->d_part_color, &c->d_part_albedo, &c->d_part_normal })
         b->release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -270,8 +272,76 @@ template <int I, bool S, bool S16> static int launch_lds(hjr_ctx* c, const KPara
     const bool full = kp.aov_albedo || kp.aov_normal || kp.tex_desc || kp.sky_tex;
     return full ? launch_lds2<I, S, S16, true>(c, kp, n_items, st) : launch_lds2<I, S, S16, false>(c, kp, n_items, st);
 }
+// Workgroup-local wavefront kernel (hjr_wavefront.hip.h): one 1024-thread workgroup per CU for every layout
+template <int I, bool S, bool LDS, bool S16, int W, bool A> static int launch_wf2(hjr_ctx* c, const KParams& kp, uint64_t n_items, hipStream_t st)
+{
+    uint32_t cap = 2048;
+    if (const char* e = getenv("HJR_WF_CAP")) { int v = atoi(e); if (v >= 64 && v <= 32768 && (v & (v - 1)) == 0) cap = (uint32_t)v; }
+    uint32_t short_stack = HJR_SHORT_STACK;
+    if (const char* e = getenv("HJR_SHORT_STACK")) { int v = atoi(e); if (v >= 1 && v <= 64) short_stack = (uint32_t)v; }
+    const uint32_t lds_entries = LDS ? kp.stack_depth : (kp.stack_depth < short_stack ? kp.stack_depth : short_stack);
+    const size_t scene_bytes = LDS ? ((size_t)kp.n_node_f4 + kp.n_tri_f4 + kp.n_mat_f4 + kp.n_light_f4) * 16 : 0;
+    const size_t smem = (((size_t)HJR_BLOCK_LDS * lds_entries * (S16 ? 2 : 4) + 15) / 16) * 16 + scene_bytes + 80 + (size_t)HJR_WF_QUEUES * cap * 2;
+    if (smem > 160u * 1024u) return -2;
+    auto kern = hjr_wavefront_kernel<I, S, HJR_BLOCK_LDS, LDS, S16, W, A>;
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return -1;
+    uint64_t blocks = (uint64_t)c->n_cus;
+    const uint64_t max_useful = (n_items + cap - 1) / cap;
+    if (blocks > max_useful) blocks = max_useful ? max_useful : 1;
+    KParams k2 = kp;
+    k2.wf_cap = cap;
+    k2.wf_plane_stride = (uint32_t)(blocks * cap);
+    const size_t ctx_bytes = (size_t)(A ? HJR_WF_PLANES_FULL : HJR_WF_PLANES_LEAN) * 16 * k2.wf_plane_stride;
+    if (c->d_wf_ctx.cap < ctx_bytes) {
+        c->d_wf_ctx.release();
+        if (hipMalloc(&c->d_wf_ctx.p, ctx_bytes) != hipSuccess) return -1;
+        c->d_wf_ctx.cap = ctx_bytes;
+    }
+    k2.wf_ctx = (float4*)c->d_wf_ctx.p;
+    k2.stack_lds_entries = lds_entries;
+    if (!LDS) {
+        k2.spill_stride = (uint32_t)(blocks * HJR_BLOCK_LDS);
+        const uint32_t over = kp.stack_depth > lds_entries ? kp.stack_depth - lds_entries : 0u;
+        const size_t spill_bytes = (size_t)k2.spill_stride * (over ? over : 1u) * 4;
+        if (c->d_spill.cap < spill_bytes) {
+            c->d_spill.release();
+            if (hipMalloc(&c->d_spill.p, spill_bytes) != hipSuccess) return -1;
+            c->d_spill.cap = spill_bytes;
+        }
+        k2.stack_spill = (uint32_t*)c->d_spill.p;
+        c->stats.stack_lds_entries = lds_entries;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(HJR_BLOCK_LDS), smem, st, k2);
+    return 0;
+}
+template <int I, bool S, bool LDS, bool S16, int W> static int launch_wf1(hjr_ctx* c, const KParams& kp, uint64_t n_items, hipStream_t st)
+{
+    const bool full = kp.aov_albedo || kp.aov_normal || kp.tex_desc || kp.sky_tex;
+    return full ? launch_wf2<I, S, LDS, S16, W, true>(c, kp, n_items, st) : launch_wf2<I, S, LDS, S16, W, false>(c, kp, n_items, st);
+}
+template <int I, bool S> static int launch_wf(hjr_ctx* c, const KParams& kp, uint64_t n_items, int lds_mode, hipStream_t st)
+{
+    if (lds_mode == 1) return launch_wf1<I, S, true, false, 2>(c, kp, n_items, st);
+    if (lds_mode == 2) return launch_wf1<I, S, true, true, 2>(c, kp, n_items, st);
+    if (lds_mode == 3) return launch_wf1<I, S, false, false, 2>(c, kp, n_items, st);
+    return launch_wf1<I, S, false, false, 4>(c, kp, n_items, st);
+}
 template <int I, bool S> static int launch(hjr_ctx* c, const KParams& kp, uint64_t n_items, int lds_mode, hipStream_t st)
 {
+    // HJR_PIPELINE=mega | wf selects the kernel family; both produce the same bits
+    const char* pe = getenv("HJR_PIPELINE");
+    const bool wf = pe && strcmp(pe, "wf") == 0;
+    c->stats.pipeline = wf ? 1u : 0u;
+    if (wf) {
+        int lm = lds_mode;
+        if (lm == 1) { // the wavefront kernel keeps its id queues in LDS too: fall back to 16-bit stack entries when the 32-bit ones leave no room
+            const size_t need = (size_t)HJR_BLOCK_LDS * kp.stack_depth * 4 + ((size_t)kp.n_node_f4 + kp.n_tri_f4 + kp.n_mat_f4 + kp.n_light_f4) * 16 + 80 + (size_t)HJR_WF_QUEUES * 2048 * 2 + 64;
+            if (need > HJR_LDS_BUDGET) lm = 2;
+        }
+        const int rc = launch_wf<I, S>(c, kp, n_items, lm, st);
+        if (rc != -2) return rc;
+        c->stats.pipeline = 0u; // the scene tables + queues do not fit LDS in this layout: megakernel
+    }
     if (lds_mode == 1) return launch_lds<I, S, false>(c, kp, n_items, st);
     if (lds_mode == 2) return launch_lds<I, S, true>(c, kp, n_items, st);
     if (lds_mode == 3) return launch_mem<I, S, 2>(c, kp, n_items, st); // BVH2 read from memory (HJR_BVH_WIDTH=2 knob on a big scene)
@@ -340,7 +410,8 @@ static int render_impl(hjr_ctx* c, const hjr_params* p, void* d_color, void* d_a
     }
     HIPCHK(hipMemsetAsync(c->d_work.p, 0, work_bytes, st));
     const size_t img_bytes = (size_t)p->width * p->height * 16;
-    if (world > 1 && (p->flags & HJR_FLAG_ZERO_UNOWNED)) {
+    const bool packed = (p->flags & HJR_FLAG_PACKED) != 0;
+    if (!packed && world > 1 && (p->flags & HJR_FLAG_ZERO_UNOWNED)) {
         HIPCHK(hipMemsetAsync(d_color, 0, img_bytes, st));
         if (d_albedo) HIPCHK(hipMemsetAsync(d_albedo, 0, img_bytes, st));
         if (d_normal) HIPCHK(hipMemsetAsync(d_normal, 0, img_bytes, st));
@@ -385,6 +456,7 @@ static int render_impl(hjr_ctx* c, const hjr_params* p, void* d_color, void* d_a
     kp.width = p->width; kp.height = p->height; kp.spp = p->spp; kp.frame = p->frame; kp.seed = p->seed; kp.integrator = p->integrator;
     kp.tiles_x = tiles_x; kp.n_owned_items = (uint32_t)n_items;
     kp.rank = p->rank; kp.world = world;
+    kp.packed = packed ? 1u : 0u;
     for (int k = 0; k < 3; k++) {
         kp.cam_pos[k] = p->camera.pos[k]; kp.cam_dir[k] = p->camera.dir[k];
         kp.cam_up[k] = p->camera.up[k]; kp.cam_right[k] = p->camera.right[k];
@@ -486,19 +558,29 @@ static int fetch_stats(hjr_ctx* c, hipStream_t st)
     uint64_t* dst = &c->stats.samples;
     for (int i = 0; i < 10; i++) dst[i] = h[i];
     c->stats.stack_overflow_pushes = h[10];
+#ifdef HJR_WF_WATCHDOG
+    { // diagnostic build only: did a workgroup of the wavefront kernel give up waiting?
+        unsigned long long wd[19];
+        HIPCHK(hipMemcpy(wd, (char*)c->d_work.p + 16 + HJR_NSTAT * 8, sizeof(wd), hipMemcpyDeviceToHost));
+        unsigned int word = 0;
+        (void)hipMemcpyFromSymbol(&word, HIP_SYMBOL(wf_watchdog_word), 4);
+        unsigned int where[8] = { 0 };
+        (void)hipMemcpyFromSymbol(where, HIP_SYMBOL(wf_where), sizeof(where));
+        if (where[1] | where[2] | where[3] | where[4] | where[5]) fprintf(stderr, "[hjr wf watchdog] deadline hit in: take %u, push-wait %u, scheduler %u, trace loop %u, pop %u\n", where[1], where[2], where[3], where[4], where[5]);
+        if (wd[0] || word) {
+            fprintf(stderr, "[hjr wf watchdog] %llu workgroup-waves gave up (take-spin word %08x); first: block %llu live %llu items_held %llu\n", wd[0], word, wd[17], wd[16], wd[18]);
+            for (int q = 0; q < 5; q++) fprintf(stderr, "   queue %d: count %llu head %llu tail %llu\n", q, wd[1 + q], wd[6 + q], wd[11 + q]);
+        }
+    }
+#endif
 #ifdef HJR_TIMING
-    {
-        unsigned long long tk[20];
+    { // diagnostic build only: wave-clock shares of the megakernel's loop phases and lane occupancies
+        unsigned long long tk[8];
         HIPCHK(hipMemcpy(tk, (char*)c->d_work.p + 16 + HJR_NSTAT * 8, sizeof(tk), hipMemcpyDeviceToHost));
-        double tot = 0; for (int i = 0; i < 6; i++) tot += (double)tk[i];
-        for (int i = 14; i < 18; i++) tot += (double)tk[i];
-        fprintf(stderr, "[hjr timing]   finer: refill %.1f%%  resolve shadow/finish %.1f%%  hit program %.1f%%\n", 100 * tk[14] / tot, 100 * tk[15] / tot, 100 * tk[16] / tot);
-        fprintf(stderr, "[hjr timing] rr/regen %.1f%%  trace %.1f%%  resolve+hit %.1f%%  nee(light+eval) %.1f%%  bsdf sample %.1f%%  rest %.1f%%  (total %.3g wave-clocks)\n",
-                100 * tk[0] / tot, 100 * tk[1] / tot, 100 * tk[2] / tot, 100 * tk[3] / tot, 100 * tk[4] / tot, 100 * tk[5] / tot, tot);
-        if (tk[8]) fprintf(stderr, "[hjr timing]   lanes per wave iteration: closest ray %.1f, shadow ray %.1f, shading %.1f (msGGX %.1f, glass %.1f); shading executed in %.0f%% of iterations\n",
-                (double)tk[9] / tk[8], (double)tk[10] / tk[8], (double)tk[11] / tk[8], (double)tk[12] / tk[8], (double)tk[13] / tk[8], 100.0 * tk[18] / tk[8]);
-        if (tk[18]) fprintf(stderr, "[hjr timing]   shading lanes in rounds that shade: %.1f; lanes serviced per round: %.1f\n", (double)tk[11] / tk[18], (double)tk[19] / tk[8]);
-        fprintf(stderr, "[hjr timing]   inside trace: inner-node loop %.1f%%  leaf/triangles+switch %.1f%% (of total)\n", 100 * tk[6] / tot, 100 * tk[7] / tot);
+        const double tot = (double)tk[0] + (double)tk[1] + (double)tk[2];
+        if (tot > 0) fprintf(stderr, "[hjr timing] roulette/refill/regeneration %.1f%%  fused trace %.1f%%  resolve + hit program + shading %.1f%%  (%.3g wave-clocks)\n",
+                             100 * tk[0] / tot, 100 * tk[1] / tot, 100 * tk[2] / tot, tot);
+        if (tk[3]) fprintf(stderr, "[hjr timing] lanes per round: closest-hit ray %.1f, shadow ray %.1f, serviced %.1f\n", (double)tk[4] / tk[3], (double)tk[5] / tk[3], (double)tk[6] / tk[3]);
     }
 #endif
     return HJR_OK;
@@ -619,6 +701,29 @@ extern "C" int hjr_selftest_stack16(void)
     return 0;
 }
 
+extern "C" int hjr_pack_tiles_device(hjr_ctx* c, const void* d_frame, uint32_t w, uint32_t h, uint32_t rank, uint32_t world, void* d_packed, void* hip_stream)
+{
+    if (!c || !d_frame || !d_packed || w == 0 || h == 0 || world == 0 || rank >= world) { set_error("hjr_pack_tiles_device: bad argument"); return HJR_ERR_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    const uint32_t n = hjr_owned_tiles(w, h, rank, world);
+    if (n == 0) return HJR_OK;
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    hipLaunchKernelGGL(hjr_pack_tiles_kernel, dim3((unsigned)(((size_t)n * 64 + 255) / 256)), dim3(256), 0, st, (const float4*)d_frame, (float4*)d_packed, w, h, (w + HJR_TILE - 1) / HJR_TILE, n, rank, world);
+    HIPCHK(hipGetLastError());
+    return HJR_OK;
+}
+extern "C" int hjr_unpack_tiles_device(hjr_ctx* c, const void* d_packed, uint32_t w, uint32_t h, uint32_t rank, uint32_t world, void* d_frame, void* hip_stream)
+{
+    if (!c || !d_frame || !d_packed || w == 0 || h == 0 || world == 0 || rank >= world) { set_error("hjr_unpack_tiles_device: bad argument"); return HJR_ERR_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    const uint32_t n = hjr_owned_tiles(w, h, rank, world);
+    if (n == 0) return HJR_OK;
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    hipLaunchKernelGGL(hjr_unpack_tiles_kernel, dim3((unsigned)(((size_t)n * 64 + 255) / 256)), dim3(256), 0, st, (const float4*)d_packed, (float4*)d_frame, w, h, (w + HJR_TILE - 1) / HJR_TILE, n, rank, world);
+    HIPCHK(hipGetLastError());
+    return HJR_OK;
+}
+
 extern "C" int hjr_synchronize(hjr_ctx* c)
 {
     if (!c) { set_error("hjr_synchronize: null context"); return HJR_ERR_ARG; }
@@ -649,6 +754,7 @@ extern "C" int hjr_render(hjr_ctx* c, const hjr_params* p, float* color, float* 
     HIPCHK(hipSetDevice(c->device));
     const size_t bytes = (size_t)p->width * p->height * 16;
     if (bytes == 0) { set_error("hjr_render: empty image"); return HJR_ERR_ARG; }
+    if (p->flags & HJR_FLAG_PACKED) { set_error("hjr_render: HJR_FLAG_PACKED is a device-buffer layout (hjr_render_device)"); return HJR_ERR_ARG; }
     DevBuf* bufs[3] = { &c->d_color, &c->d_albedo, &c->d_normal };
     float* host[3] = { color, albedo, normal };
     for (int i = 0; i < 3; i++) {

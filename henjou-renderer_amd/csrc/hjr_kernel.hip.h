@@ -149,7 +149,7 @@ HD void start_path(const KParams& P, PathState& ps, uint32_t px, uint32_t py, ui
     f3 cd = V(P.cam_dir[0], P.cam_dir[1], P.cam_dir[2]);
     f3 cu = V(P.cam_up[0], P.cam_up[1], P.cam_up[2]);
     f3 cr = V(P.cam_right[0], P.cam_right[1], P.cam_right[2]);
-    // the ray origin is the (wave-uniform) camera position: not stored per lane, see `fresh` in the kernel
+    // the ray origin is the (wave-uniform) camera position: not stored per lane, see LaneCtx::fresh
     ps.rd = normalize(cd * P.cam_f + cr * u + cu * v);
     ps.thr = V1(1.0f);
     ps.depth = 0;
@@ -164,8 +164,358 @@ HD void start_path(const KParams& P, PathState& ps, uint32_t px, uint32_t py, ui
 // workgroup of BLOCK threads per CU shares the copy.  Chosen by the host when the scene fits (hjr_device.hip).
 extern __shared__ float4 hjr_smem[];
 
+// ------------------------------------------------------------------ per-lane path context and the two halves of a bounce
+// Everything a lane carries from one bounce to the next.  The megakernel keeps it in registers for the lifetime of the lane;
+// the workgroup-local wavefront kernel (hjr_wavefront.hip.h) parks it in memory between its trace and shade stages.  Both run
+// the SAME two functions on it — bounce_pre_trace (Russian roulette, ray-queue refill, path regeneration) and
+// bounce_post_trace (shadow-ray resolution, closest-hit / miss program, NEE / MIS, BSDF sampling) — so every pixel is the same
+// bit pattern whichever kernel produced it.
+struct LaneCtx {
+    bool has_item, dead, path_live;
+    bool fin_pending;   // a finished path whose L still waits for its last NEE shadow ray
+    bool write_pending; // the item's last sample is finished; sums go out once fin_pending is resolved
+    bool sh_valid;      // pending NEE shadow ray of the bounce shaded last
+    bool fresh;         // the closest-hit ray of this lane starts at the camera (ps.ro is then the origin of the pending shadow ray only)
+    uint32_t item;      // px | py << 13 | chunk << 26
+    uint32_t s;         // current sample of the item's run
+    uint32_t it_cost;   // closest-hit rays traced for the current item (feeds the measured-cost tile order)
+    f3 sumL, sumA, sumN;
+    f3 sh_d, sh_contrib; // pending shadow ray: direction and the contribution that is added iff it is unoccluded
+    float sh_tmax;
+    // Register diet (the LDS variant runs at 128 VGPRs): pixel and chunk share one word; ps.ro doubles as the origin of the pending
+    // shadow ray (a regenerated path starts at the wave-uniform camera position: `fresh`); ps.L keeps the finished path's radiance
+    // while fin_pending (the new path's L is 0 until that is resolved).
+    PathState ps;
+};
+HD void ctx_reset(LaneCtx& c)
+{
+    c.has_item = c.dead = c.path_live = c.fin_pending = c.write_pending = c.sh_valid = false;
+    c.fresh = true;
+    c.item = c.s = c.it_cost = 0u;
+    c.sumL = c.sumA = c.sumN = c.sh_d = c.sh_contrib = V1(0.0f);
+    c.sh_tmax = 0.0f;
+    c.ps.ro = c.ps.rd = c.ps.thr = c.ps.L = V1(0.0f);
+    c.ps.depth = 0; c.ps.rng_depth = 0;
+}
+#define HJR_PX(c) ((c).item & 0x1fffu)
+#define HJR_PY(c) (((c).item >> 13) & 0x1fffu)
+#define HJR_CHUNK(c) ((c).item >> 26)
+#define HJR_S_END(c) min((HJR_CHUNK(c) + 1u) * P.chunk_spp, P.spp)
+
+// this wave's private range of the global work queue (wave-uniform).  `held` (wavefront kernel; null in the megakernel) counts the
+// items that the waves of one workgroup hold in their private ranges: there a context is handed from wave to wave, so one that
+// finds the global queue dry in the hands of a wave with an empty range must not die while another wave still has items for it.
+struct WaveRange { uint32_t next, end; bool exhausted; uint32_t* held; };
+
+// NaN/Inf guard + ordered accumulation of one finished sample
+template <bool STATS> HD void finish_sample(LaneCtx& c, f3 L, unsigned long long* lc)
+{
+    float sum = L.x + L.y + L.z;
+    if (!(sum - sum == 0.0f)) { L = V1(0.0f); if (STATS) lc[9] += 1; }
+    c.sumL = c.sumL + L;
+    if (STATS) lc[0] += 1;
+}
+// sample bookkeeping at the end of a path (independent of the radiance value)
+HD void close_sample(const KParams& P, LaneCtx& c)
+{
+    c.s++;
+    c.path_live = false;
+    if (c.s == HJR_S_END(c)) { c.write_pending = true; c.has_item = false; }
+}
+template <bool AOVS> HD void write_out(const KParams& P, LaneCtx& c)
+{
+    const float inv_spp = 1.0f / (float)P.spp;
+    // AOV element of the pixel: row-major frame, or (HJR_FLAG_PACKED) this rank's tiles back to back: (owned tile index) * 64 + pixel in tile
+    const size_t pix = P.packed ? (size_t)(((HJR_PY(c) / HJR_TILE) * P.tiles_x + HJR_PX(c) / HJR_TILE) / P.world) * 64u + ((HJR_PY(c) & 7u) * 8u + (HJR_PX(c) & 7u))
+                                : (size_t)HJR_PX(c) + (size_t)HJR_PY(c) * P.width;
+    if (P.n_chunks == 1u) { // the item is the whole pixel: mean = chunk sum * (1 / spp)
+        P.aov_color[pix] = make_float4(c.sumL.x * inv_spp, c.sumL.y * inv_spp, c.sumL.z * inv_spp, 1.0f);
+        if (AOVS && P.aov_albedo) P.aov_albedo[pix] = make_float4(c.sumA.x * inv_spp, c.sumA.y * inv_spp, c.sumA.z * inv_spp, 1.0f);
+        if (AOVS && P.aov_normal) P.aov_normal[pix] = make_float4(c.sumN.x * inv_spp, c.sumN.y * inv_spp, c.sumN.z * inv_spp, 1.0f);
+    } else { // chunk sum -> HBM; hjr_finalize_kernel adds the chunks of a pixel in chunk order.  The buffers hold this rank's
+             // tiles only: slot = ((chunk * owned tiles) + owned tile index) * 64 + pixel in tile
+        const uint32_t otile = ((HJR_PY(c) / HJR_TILE) * P.tiles_x + HJR_PX(c) / HJR_TILE) / P.world;
+        const size_t slot = ((size_t)HJR_CHUNK(c) * P.n_owned_tiles + otile) * 64u + ((HJR_PY(c) & 7u) * 8u + (HJR_PX(c) & 7u));
+        P.part_color[slot] = make_float4(c.sumL.x, c.sumL.y, c.sumL.z, 0.0f);
+        if (AOVS && P.part_albedo) P.part_albedo[slot] = make_float4(c.sumA.x, c.sumA.y, c.sumA.z, 0.0f);
+        if (AOVS && P.part_normal) P.part_normal[slot] = make_float4(c.sumN.x, c.sumN.y, c.sumN.z, 0.0f);
+    }
+    c.write_pending = false;
+}
+
+// ---- first half of a bounce.  ALL 64 lanes of the wave must call it together (ballots and shuffles inside); `active` is
+// false for lanes that sit this round out (megakernel: lanes whose traversal is carried over; wavefront: lanes without a
+// context).  On return `tracing` says whether the lane has a closest-hit ray to trace (origin: camera if c.fresh, else c.ps.ro;
+// direction c.ps.rd) and c.sh_valid whether a shadow ray (origin c.ps.ro, direction c.sh_d, tmax c.sh_tmax) goes with it.
+template <bool STATS, bool AOVS>
+HD void bounce_pre_trace(const KParams& P, LaneCtx& c, WaveRange& wr, const bool active, bool& tracing, unsigned long long* lc)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    // ---- Russian roulette (rt.h:173-179) with in-place path regeneration: a lane whose path dies here starts its
+    //      next sample immediately, so it still has a closest-hit ray for this iteration's trace.  The dead path's
+    //      radiance is final only after its pending shadow ray (fused into the same trace) is resolved.
+    if (active) {
+        if (c.has_item && c.path_live) { // continuing path
+            const float russian_p = fmaxf(c.ps.thr.x, fmaxf(c.ps.thr.y, c.ps.thr.z));
+            CMJState rr = path_rng(P, HJR_PX(c), HJR_PY(c), c.s, c.ps.rng_depth);
+            const float xi_rr = cmj_1d(rr);
+            c.ps.rng_depth = rr.depth;
+            if (russian_p < xi_rr) {
+                if (c.sh_valid) { c.fin_pending = true; close_sample(P, c); } // radiance final once the pending shadow ray is resolved
+                else { // nothing pending: the sample is final now, and if it was the item's last one the lane refills below
+                    finish_sample<STATS>(c, c.ps.L, lc);
+                    c.ps.L = V1(0.0f);
+                    close_sample(P, c);
+                    if (c.write_pending) write_out<AOVS>(P, c);
+                }
+            } else c.ps.thr = c.ps.thr / russian_p;
+        }
+    }
+
+    // ---- ray-queue refill (ballot + mbcnt prefix): idle lanes take consecutive items from the wave's private range
+    //      [wr.next, wr.end); when it runs dry the wave fetches the next 64 items with ONE atomic on the global head.
+    {
+        const bool need = active && !c.has_item && !c.dead && !c.write_pending && !c.fin_pending && !c.sh_valid;
+        const unsigned long long m = __ballot(need);
+        if (m) {
+            const uint32_t n = (uint32_t)__popcll(m);
+            const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            uint32_t q = wr.next + prefix;          // wave-uniform wr.next / wr.end
+            const uint32_t have = wr.end - wr.next; // items left in the private range
+            if (n > have) {                         // not enough: lanes beyond `have` come from a fresh range
+                // once a wave has seen the queue run dry it never touches the head again (wave-uniform flag): the 32-bit head
+                // overshoots n_owned_items by at most 64 per wave of the grid and cannot wrap (hjr_device.hip keeps that margin)
+                uint32_t base = 0xffffffffu;
+                if (!wr.exhausted) {
+                    if (lane == 0) base = atomicAdd(P.queue_head, 64u);
+                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                    wr.exhausted = base >= P.n_owned_items;
+                }
+                if (wr.held && have && lane == 0) atomicSub(wr.held, have); // the rest of the old range is handed out now
+                if (wr.exhausted) {
+                    if (prefix >= have) q = 0xffffffffu;
+                    wr.next = wr.end = 0u;
+                } else {
+                    if (prefix >= have) q = base + (prefix - have);
+                    wr.end = min(base + 64u, P.n_owned_items); // a range never reaches past the last item
+                    wr.next = min(base + (n - have), wr.end);
+                    if (wr.held && lane == 0 && wr.end != wr.next) atomicAdd(wr.held, wr.end - wr.next); // what stays unassigned
+                }
+            } else { wr.next += n; if (wr.held && lane == 0) atomicSub(wr.held, n); }
+            // measured cost of a tile (orders the tiles of the next frame, hjr_cost_hist_kernel): a lane sums the rays of its
+            // consecutive items of one tile and flushes when it moves on; lanes leaving the same tile together (the usual
+            // case) share one atomic.  All lanes are here (m is wave-uniform), so the shuffles below are well defined.
+            const uint32_t old_tile = (HJR_PY(c) / HJR_TILE) * P.tiles_x + HJR_PX(c) / HJR_TILE;
+            uint32_t new_tile = 0xffffffffu;
+            if (need && q < P.n_owned_items) new_tile = P.tile_order ? P.tile_order[(q >> 6) / P.n_chunks] : ((q >> 6) / P.n_chunks) * P.world + P.rank;
+            bool flush = need && P.tile_cost && c.it_cost != 0u && new_tile != old_tile;
+            while (__ballot(flush)) {
+                const int leader = __ffsll((long long)__ballot(flush)) - 1;
+                const uint32_t t = (uint32_t)__shfl((int)old_tile, leader);
+                const bool mine = flush && old_tile == t;
+                uint32_t v = mine ? c.it_cost : 0u;
+                for (int off = 32; off > 0; off >>= 1) v += (uint32_t)__shfl_xor((int)v, off);
+                if ((int)lane == leader) atomicAdd(&P.tile_cost[t / P.world], v);
+                if (mine) { c.it_cost = 0u; flush = false; }
+            }
+            if (need) {
+                if (q < P.n_owned_items) {
+                    // item q = ((owned tile * n_chunks) + chunk) * 64 + pixel-in-tile: the 64 lanes of a wave start on one
+                    // tile and one sample chunk (coherent primary rays)
+                    const uint32_t tc = q >> 6;
+                    const uint32_t tile = new_tile;
+                    const uint32_t chunk = tc % P.n_chunks;
+                    const uint32_t tx = tile % P.tiles_x, ty = tile / P.tiles_x;
+                    const uint32_t px = tx * HJR_TILE + (q & 7u);
+                    const uint32_t py = ty * HJR_TILE + ((q >> 3) & 7u);
+                    if (px < P.width && py < P.height) {
+                        c.has_item = true; c.path_live = false;
+                        c.item = px | (py << 13) | (chunk << 26);
+                        c.s = chunk * P.chunk_spp;
+                        c.sumL = V1(0.0f); c.sumA = V1(0.0f); c.sumN = V1(0.0f);
+                    }
+                } else c.dead = !(wr.held && __hip_atomic_load(wr.held, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u); // wavefront: another wave may still hold items
+            }
+        }
+    }
+
+    if (active) {
+        if (c.has_item && !c.path_live) {
+            start_path(P, c.ps, HJR_PX(c), HJR_PY(c), c.s);
+            if (!c.fin_pending) c.ps.L = V1(0.0f); // while fin_pending, ps.L still belongs to the finished path
+            c.path_live = true; c.fresh = true;
+            // the new path's own roulette draw: throughput is (1,1,1), so russian_p = 1 > xi for every xi in [0,1) and
+            // thr / 1 == thr; only the stream position moves
+            c.ps.rng_depth += 1u;
+        }
+        tracing = c.has_item;
+    }
+}
+
+// ---- second half of a bounce, for a lane whose rays of this round are resolved: `occluded` answers the pending shadow ray
+// (if c.sh_valid), `h` the closest-hit ray (if tracing).  Lane-private: no cross-lane operation inside.
+template <int INTEGRATOR, bool STATS, bool AOVS, int WIDTH, int BLOCK, typename ST>
+HD void bounce_post_trace(const KParams& P, const float4* nodes, const float4* tris, const float4* mats, const float4* lights, LaneCtx& c,
+                          const bool tracing, const bool occluded, const Hit& h, ST& stack, unsigned long long* lc)
+{
+    PathState& ps = c.ps;
+    if (c.sh_valid) { // `if (!light_shot.is_hit) LTE += ...` (rt.h:245-259), added to the path the shadow ray belongs to
+        if (!occluded) ps.L = ps.L + c.sh_contrib; // ps.L is the finished path's radiance while fin_pending
+        c.sh_valid = false;
+    }
+    if (c.fin_pending) {
+        finish_sample<STATS>(c, ps.L, lc);
+        ps.L = V1(0.0f); // from here on ps.L belongs to the path that was regenerated (or to nothing)
+        c.fin_pending = false;
+        if (c.write_pending) write_out<AOVS>(P, c);
+    }
+    if (!tracing) return;
+
+    c.it_cost++;
+    HitInfo prd;
+    hit_program<STATS, AOVS>(P, tris, mats, h, ps.rd, prd, lc);
+    if (AOVS && ps.depth == 0) { c.sumA = c.sumA + prd.surf.basecolor; c.sumN = c.sumN + prd.normal; } // rt.h:191-194
+    if (!prd.is_hit || prd.is_light) {
+        // NEE / MIS count emission only at depth 0 (rt.h:196-208, 318-330); Pathtrace always (rt.h:118-126)
+        if (INTEGRATOR == HJR_INTEGRATOR_PT_ || ps.depth == 0) ps.L = ps.L + ps.thr * prd.emission;
+        finish_sample<STATS>(c, ps.L, lc);
+        close_sample(P, c);
+        if (c.write_pending) write_out<AOVS>(P, c);
+        return;
+    }
+    CMJState st = path_rng(P, HJR_PX(c), HJR_PY(c), c.s, ps.rng_depth);
+    const Surface& sf = prd.surf;
+    f3 t, b;
+    const f3 n = prd.normal;
+    orthonormal_basis(n, t, b);
+    const f3 local_wo = world_to_local(-ps.rd, t, n, b);
+
+    if (INTEGRATOR != HJR_INTEGRATOR_PT_ && P.n_lights >= 1u) { // light_prim_count < 1: no contribution (UB in the reference)
+        float light_pdf;
+        f3 light_color, light_normal;
+        const f3 light_position = light_sample(P, lights, st, light_pdf, light_normal, light_color);
+        if (STATS) lc[8] += 1;
+        const f3 so = prd.position;
+        f3 sd;
+        float light_distance;
+        if (INTEGRATOR == HJR_INTEGRATOR_NEE_) { // rt.h:230-233
+            sd = normalize(light_position - so);
+            light_distance = length3(light_position - so);
+        } else { // rt.h:352-354
+            sd = light_position - so;
+            light_distance = length3(sd);
+            sd = normalize(sd);
+        }
+        // the contribution is fully determined here; only whether it is added depends on the shadow ray, which is
+        // traced fused with the next closest-hit ray in the next round
+        const float cosine1 = absdot(n, sd);
+        const float cosine2 = absdot(light_normal, -sd);
+        const f3 local_wi = world_to_local(sd, t, n, b);
+        const f3 bsdf = bsdf_eval(P, sf, local_wo, local_wi);
+        const float G = cosine2 / (light_distance * light_distance);
+        if (INTEGRATOR == HJR_INTEGRATOR_NEE_) {
+            c.sh_contrib = (ps.thr * ((bsdf * G * cosine1) / light_pdf)) * light_color; // rt.h:258
+        } else {
+            const float pt_pdf = bsdf_pdf(sf, local_wo, local_wi) * G;
+            const float mis_weight = light_pdf / (light_pdf + pt_pdf);
+            c.sh_contrib = ((ps.thr * ((bsdf * G * cosine1) / light_pdf)) * mis_weight) * light_color; // rt.h:378
+        }
+        c.sh_d = sd; c.sh_tmax = light_distance - 0.001f; // origin = prd.position = ps.ro below
+        // an exactly-zero contribution (every hit on the glass lobe, whose evaluateBSDF is 0) cannot change L whatever
+        // the shadow ray returns (x + 0 == x): skip the trace.  A NaN contribution still goes through.
+        c.sh_valid = !(c.sh_contrib.x == 0.0f && c.sh_contrib.y == 0.0f && c.sh_contrib.z == 0.0f);
+    }
+
+    if (INTEGRATOR == HJR_INTEGRATOR_MIS_) { // BSDF-sampled light hit, rt.h:383-420
+        // MIS adds this term AFTER the NEE term of the same bounce (rt.h:378 then :414/:418); the NEE term is still
+        // pending, so resolve its shadow ray now to keep the order of the float additions
+        if (c.sh_valid) {
+            Hit shh;
+            Counters cn; cn.box = 0; cn.tri = 0;
+            const bool occ = traverse<true, STATS, WIDTH, BLOCK, ST>(nodes, tris, prd.position, c.sh_d, 0.001f, c.sh_tmax, shh, stack, cn);
+            if (STATS) { lc[2] += 1; lc[5] += cn.box; lc[6] += cn.tri; }
+            if (!occ) ps.L = ps.L + c.sh_contrib;
+            c.sh_valid = false;
+        }
+        float pt_pdf = 1.0f; // uninitialised in the reference when msGGX returns early; defined as 1
+        f3 local_wi = V(0.0f, 1.0f, 0.0f);
+        const f3 brdf = bsdf_sample(P, sf, local_wo, local_wi, pt_pdf, st);
+        const f3 wi = local_to_world(local_wi, t, n, b);
+        const float cosine1 = absdot(wi, n);
+        HitInfo lh;
+        ray_trace<STATS, AOVS, WIDTH, BLOCK, ST>(P, nodes, tris, mats, prd.position, wi, lh, stack, lc);
+        if (lh.is_hit) {
+            if (lh.is_light) {
+                const float cosine2 = absdot(-wi, lh.normal);
+                const float light_distance = length3(lh.position - prd.position);
+                const float invG = light_distance * light_distance / cosine2;
+                // getLightPDF(prim, inst) (light_sample.h:77-92): 1 / (area * light_prim_count), area from the light
+                // table's world vertices (== transform_position of the same object vertices); the table row of an
+                // emissive triangle is found by its global prim id (l4.w)
+                float lp = 0.0f;
+                if (!sf.is_specular) {
+                    for (uint32_t li = 0; li < P.n_lights; li++) {
+                        const float4* Lr = lights + li * HJR_LIGHT_F4;
+                        if (f2bits(Lr[4].w) == lh.prim) {
+                            const float4 a0 = Lr[0], a1 = Lr[1], a2 = Lr[2];
+                            const f3 cr = cross(V(a1.x, a1.y, a1.z) - V(a0.x, a0.y, a0.z), V(a2.x, a2.y, a2.z) - V(a0.x, a0.y, a0.z));
+                            const float area = length3(cr) * 0.5f;
+                            lp = 1.0f / (area * P.n_lights);
+                            break;
+                        }
+                    }
+                    lp = lp * invG;
+                }
+                const float mis_weight = pt_pdf / (pt_pdf + lp);
+                ps.L = ps.L + ((((ps.thr * mis_weight) * cosine1) * lh.emission) * brdf) / pt_pdf; // rt.h:414
+            }
+        } else {
+            ps.L = ps.L + (((ps.thr * brdf) * cosine1) * lh.emission) / pt_pdf; // rt.h:418
+        }
+    }
+
+    float pdf = 1.0f;
+    f3 local_wi = V(0.0f, 1.0f, 0.0f);
+    if (INTEGRATOR != HJR_INTEGRATOR_PT_) (void)cmj_2d(st); // drawn and discarded by the reference (rt.h:266, 426)
+    const f3 bsdf = bsdf_sample(P, sf, local_wo, local_wi, pdf, st);
+    const f3 wi = local_to_world(local_wi, t, n, b);
+    ps.thr = ps.thr * ((bsdf * fabsf(dot(wi, n))) / pdf); // rt.h:274
+    ps.ro = prd.position;
+    ps.rd = wi;
+    c.fresh = false;
+    ps.rng_depth = st.depth;
+    ps.depth++;
+    if (ps.depth == 10) { // MaxDepth (rt.h:166): the path is over; its last shadow ray, if any, is still pending
+        if (c.sh_valid) { c.fin_pending = true; close_sample(P, c); }
+        else {
+            finish_sample<STATS>(c, ps.L, lc);
+            ps.L = V1(0.0f);
+            close_sample(P, c);
+            if (c.write_pending) write_out<AOVS>(P, c);
+        }
+    }
+}
+
+// stages the scene tables of an LDS-resident layout behind the traversal stacks (all threads of the workgroup; ends with a barrier)
+template <typename SE, int BLOCK>
+HD void stage_scene_in_lds(const KParams& P, float4* base, const float4*& nodes, const float4*& tris, const float4*& mats, const float4*& lights)
+{
+    float4* l_nodes = base;
+    float4* l_tris = l_nodes + P.n_node_f4;
+    for (uint32_t i = threadIdx.x; i < P.n_node_f4; i += BLOCK) l_nodes[i] = P.nodes[i];
+    for (uint32_t i = threadIdx.x; i < P.n_tri_f4; i += BLOCK) l_tris[i] = P.tri_geom[i];
+    // the (small) material and light tables ride along: one LDS read instead of an L2 round trip per shaded hit
+    float4* l_mats = l_tris + P.n_tri_f4;
+    float4* l_lights = l_mats + P.n_mat_f4;
+    for (uint32_t i = threadIdx.x; i < P.n_mat_f4; i += BLOCK) l_mats[i] = P.materials[i];
+    for (uint32_t i = threadIdx.x; i < P.n_light_f4; i += BLOCK) l_lights[i] = P.lights[i];
+    __syncthreads();
+    nodes = l_nodes; tris = l_tris; mats = l_mats; lights = l_lights;
+}
+
+// ------------------------------------------------------------------ the megakernel
 // AOVS = the "full" variant: albedo / normal AOV sums, material textures and the equirect sky texture; the lean variant
-// (colour only, untextured scene, constant sky) saves registers and is what the headline benchmark runs
+// (colour only, untextured scene, constant sky) saves registers
 template <int INTEGRATOR, bool STATS, int BLOCK, bool LDSBVH, bool STACK16, int WIDTH, bool AOVS>
 __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_render_kernel(const KParams P)
 {
@@ -182,382 +532,54 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
     const float4* tris = P.tri_geom;
     const float4* mats = P.materials;
     const float4* lights = P.lights;
-    if (LDSBVH) {
-        float4* l_nodes = hjr_smem + (BLOCK * P.stack_depth * (uint32_t)sizeof(SE) + 15u) / 16u;
-        float4* l_tris = l_nodes + P.n_node_f4;
-        for (uint32_t i = threadIdx.x; i < P.n_node_f4; i += BLOCK) l_nodes[i] = P.nodes[i];
-        for (uint32_t i = threadIdx.x; i < P.n_tri_f4; i += BLOCK) l_tris[i] = P.tri_geom[i];
-        // the (small) material and light tables ride along: one LDS read instead of an L2 round trip per shaded hit
-        float4* l_mats = l_tris + P.n_tri_f4;
-        float4* l_lights = l_mats + P.n_mat_f4;
-        for (uint32_t i = threadIdx.x; i < P.n_mat_f4; i += BLOCK) l_mats[i] = P.materials[i];
-        for (uint32_t i = threadIdx.x; i < P.n_light_f4; i += BLOCK) l_lights[i] = P.lights[i];
-        __syncthreads();
-        nodes = l_nodes;
-        tris = l_tris;
-        mats = l_mats;
-        lights = l_lights;
-    }
+    if (LDSBVH) stage_scene_in_lds<SE, BLOCK>(P, hjr_smem + (BLOCK * P.stack_depth * (uint32_t)sizeof(SE) + 15u) / 16u, nodes, tris, mats, lights);
 
     unsigned long long lc[HJR_NSTAT];
     if (STATS) for (int i = 0; i < HJR_NSTAT; i++) lc[i] = 0;
 
-    bool has_item = false, dead = false, path_live = false;
-    bool fin_pending = false;   // a finished path whose L still waits for its last NEE shadow ray
-    bool write_pending = false; // the item's last sample is finished; sums go out once fin_pending is resolved
-    bool sh_valid = false;      // pending NEE shadow ray of the bounce shaded in the previous iteration
-    // Register diet (the LDS variant runs at 128 VGPRs): pixel and chunk share one word; ps.ro doubles as the origin of the
-    // pending shadow ray (a regenerated path starts at the wave-uniform camera position: `fresh`); ps.L keeps the finished
-    // path's radiance while fin_pending (the new path's L is 0 until that is resolved).
-    bool fresh = true;          // the closest-hit ray of this lane starts at the camera
+    LaneCtx c;
+    ctx_reset(c);
+    WaveRange wr; wr.next = wr.end = 0u; wr.exhausted = false; wr.held = nullptr;
     bool inflight = false;      // carry-over: this lane's traversal continues in the next round (it skips everything else)
     bool tracing = false, occluded = false;
     Hit h;
     TravCarry tc; tc.cur = HJR_TRAV_DONE; tc.sp = 0; tc.phase = 2;
-    uint32_t item = 0;          // px | py << 13 | chunk << 26
-    uint32_t s = 0;
-    uint32_t w_next = 0, w_end = 0; // this wave's private item range (wave-uniform)
-    bool exhausted = false;         // wave-uniform: the global queue has run dry
-    uint32_t it_cost = 0;           // closest-hit rays traced for the current item
-    f3 sumL = V1(0.0f), sumA = V1(0.0f), sumN = V1(0.0f);
-    f3 sh_d = V1(0.0f), sh_contrib = V1(0.0f);
-    float sh_tmax = 0.0f;
-#define HJR_PX (item & 0x1fffu)
-#define HJR_PY ((item >> 13) & 0x1fffu)
-#define HJR_CHUNK (item >> 26)
-#define HJR_S_END min((HJR_CHUNK + 1u) * P.chunk_spp, P.spp)
-    PathState ps;
-    ps.ro = ps.rd = ps.thr = ps.L = V1(0.0f);
-    ps.depth = 0;
-    ps.rng_depth = 0;
-    const float inv_spp = 1.0f / (float)P.spp;
 #ifdef HJR_TIMING
-    // diagnostic build: wave-clock shares of the loop's phases, summed per wave into P.stats[10..15] (never in the shipped build)
-    unsigned long long tk[6] = { 0, 0, 0, 0, 0, 0 }, tk6 = 0, tk7 = 0, tx[4] = { 0, 0, 0, 0 };
-#define HJR_TICKX(i) { __builtin_amdgcn_sched_barrier(0); unsigned long long now_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); tx[i] += now_ - tstamp; tstamp = now_; }
-    bool dg_shade = false, dg_ms = false, dg_glass = false;
-    unsigned long long oc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }; // wave rounds, lanes tracing closest, lanes with a shadow ray, lanes shading, msGGX lanes, glass lanes, rounds with shading, lanes serviced
+    // diagnostic build: wave-clock shares of the loop's phases, summed per wave into P.stats[HJR_NSTAT..] (never in the shipped build)
+    unsigned long long tk[3] = { 0, 0, 0 }, oc[4] = { 0, 0, 0, 0 }; // rounds, lanes tracing closest, lanes with a shadow ray, lanes serviced
     unsigned long long tstamp = __builtin_amdgcn_s_memtime();
 #define HJR_TICK(i) { __builtin_amdgcn_sched_barrier(0); unsigned long long now_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); tk[i] += now_ - tstamp; tstamp = now_; }
-#elif defined(HJR_MARK)
-// static-analysis build: region markers in the ISA listing (count instructions between them), never shipped
-#define HJR_TICK(i) { __builtin_amdgcn_sched_barrier(0); asm volatile("; HJRMARK T" #i); __builtin_amdgcn_sched_barrier(0); }
-#define HJR_TICKX(i) { __builtin_amdgcn_sched_barrier(0); asm volatile("; HJRMARK X" #i); __builtin_amdgcn_sched_barrier(0); }
 #else
 #define HJR_TICK(i)
-#define HJR_TICKX(i)
 #endif
 
     for (;;) {
-#ifdef HJR_TIMING
-        { // wave-uniform occupancy sums of the previous round (all lanes are here; flags are lane-private)
-            const int n_sh = __popcll(__ballot(dg_shade));
-            oc[3] += n_sh; oc[4] += __popcll(__ballot(dg_ms)); oc[5] += __popcll(__ballot(dg_glass)); oc[6] += n_sh > 0 ? 1 : 0;
-            dg_shade = dg_ms = dg_glass = false;
-        }
-#endif
-        HJR_TICKX(0)
-        // NaN/Inf guard + ordered accumulation of one finished sample
-        auto finish_sample = [&](f3 L) {
-            float sum = L.x + L.y + L.z;
-            if (!(sum - sum == 0.0f)) { L = V1(0.0f); if (STATS) lc[9] += 1; }
-            sumL = sumL + L;
-            if (STATS) lc[0] += 1;
-        };
-        // sample bookkeeping at the end of a path (independent of the radiance value)
-        auto close_sample = [&]() {
-            s++;
-            path_live = false;
-            if (s == HJR_S_END) { write_pending = true; has_item = false; }
-        };
-        auto write_out = [&]() {
-            const size_t pix = (size_t)HJR_PX + (size_t)HJR_PY * P.width;
-            if (P.n_chunks == 1u) { // the item is the whole pixel: mean = chunk sum * (1 / spp)
-                P.aov_color[pix] = make_float4(sumL.x * inv_spp, sumL.y * inv_spp, sumL.z * inv_spp, 1.0f);
-                if (AOVS && P.aov_albedo) P.aov_albedo[pix] = make_float4(sumA.x * inv_spp, sumA.y * inv_spp, sumA.z * inv_spp, 1.0f);
-                if (AOVS && P.aov_normal) P.aov_normal[pix] = make_float4(sumN.x * inv_spp, sumN.y * inv_spp, sumN.z * inv_spp, 1.0f);
-            } else { // chunk sum -> HBM; hjr_finalize_kernel adds the chunks of a pixel in chunk order.  The buffers hold this rank's
-                     // tiles only: slot = ((chunk * owned tiles) + owned tile index) * 64 + pixel in tile
-                const uint32_t otile = ((HJR_PY / HJR_TILE) * P.tiles_x + HJR_PX / HJR_TILE) / P.world;
-                const size_t slot = ((size_t)HJR_CHUNK * P.n_owned_tiles + otile) * 64u + ((HJR_PY & 7u) * 8u + (HJR_PX & 7u));
-                P.part_color[slot] = make_float4(sumL.x, sumL.y, sumL.z, 0.0f);
-                if (AOVS && P.part_albedo) P.part_albedo[slot] = make_float4(sumA.x, sumA.y, sumA.z, 0.0f);
-                if (AOVS && P.part_normal) P.part_normal[slot] = make_float4(sumN.x, sumN.y, sumN.z, 0.0f);
-            }
-            write_pending = false;
-        };
-
-        // ---- Russian roulette (rt.h:173-179) with in-place path regeneration: a lane whose path dies here starts its
-        //      next sample immediately, so it still has a closest-hit ray for this iteration's trace.  The dead path's
-        //      radiance is final only after its pending shadow ray (fused into the same trace) is resolved.
-        if (!inflight) {
-            if (has_item && path_live) { // continuing path
-                const float russian_p = fmaxf(ps.thr.x, fmaxf(ps.thr.y, ps.thr.z));
-                CMJState rr = path_rng(P, HJR_PX, HJR_PY, s, ps.rng_depth);
-                const float xi_rr = cmj_1d(rr);
-                ps.rng_depth = rr.depth;
-                if (russian_p < xi_rr) {
-                    if (sh_valid) { fin_pending = true; close_sample(); } // radiance final once the pending shadow ray is resolved
-                    else { // nothing pending: the sample is final now, and if it was the item's last one the lane refills below
-                        finish_sample(ps.L);
-                        ps.L = V1(0.0f);
-                        close_sample();
-                        if (write_pending) write_out();
-                    }
-                } else ps.thr = ps.thr / russian_p;
-            }
-        }
-
-        // ---- ray-queue refill (ballot + mbcnt prefix): idle lanes take consecutive items from the wave's private range
-        //      [w_next, w_end); when it runs dry the wave fetches the next 64 items with ONE atomic on the global head.
-        {
-            const bool need = !has_item && !dead && !write_pending && !fin_pending && !sh_valid;
-            const unsigned long long m = __ballot(need);
-            if (m) {
-                const uint32_t n = (uint32_t)__popcll(m);
-                const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                uint32_t q = w_next + prefix;          // wave-uniform w_next / w_end
-                const uint32_t have = w_end - w_next;  // items left in the private range
-                if (n > have) {                        // not enough: lanes beyond `have` come from a fresh range
-                    // once a wave has seen the queue run dry it never touches the head again (wave-uniform flag): the 32-bit head
-                    // overshoots n_owned_items by at most 64 per wave of the grid and cannot wrap (hjr_device.hip keeps that margin)
-                    uint32_t base = 0xffffffffu;
-                    if (!exhausted) {
-                        if (lane == 0) base = atomicAdd(P.queue_head, 64u);
-                        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                        exhausted = base >= P.n_owned_items;
-                    }
-                    if (exhausted) {
-                        if (prefix >= have) q = 0xffffffffu;
-                        w_next = w_end = 0u;
-                    } else {
-                        if (prefix >= have) q = base + (prefix - have);
-                        w_next = base + (n - have);
-                        w_end = base + 64u;
-                    }
-                } else w_next += n;
-                // measured cost of a tile (orders the tiles of the next frame, hjr_cost_hist_kernel): a lane sums the rays of its
-                // consecutive items of one tile and flushes when it moves on; lanes leaving the same tile together (the usual
-                // case) share one atomic.  All lanes are here (m is wave-uniform), so the shuffles below are well defined.
-                const uint32_t old_tile = (HJR_PY / HJR_TILE) * P.tiles_x + HJR_PX / HJR_TILE;
-                uint32_t new_tile = 0xffffffffu;
-                if (need && q < P.n_owned_items) new_tile = P.tile_order ? P.tile_order[(q >> 6) / P.n_chunks] : ((q >> 6) / P.n_chunks) * P.world + P.rank;
-                bool flush = need && P.tile_cost && it_cost != 0u && new_tile != old_tile;
-                while (__ballot(flush)) {
-                    const int leader = __ffsll((long long)__ballot(flush)) - 1;
-                    const uint32_t t = (uint32_t)__shfl((int)old_tile, leader);
-                    const bool mine = flush && old_tile == t;
-                    uint32_t v = mine ? it_cost : 0u;
-                    for (int off = 32; off > 0; off >>= 1) v += (uint32_t)__shfl_xor((int)v, off);
-                    if ((int)lane == leader) atomicAdd(&P.tile_cost[t / P.world], v);
-                    if (mine) { it_cost = 0u; flush = false; }
-                }
-                if (need) {
-                    if (q < P.n_owned_items) {
-                        // item q = ((owned tile * n_chunks) + chunk) * 64 + pixel-in-tile: the 64 lanes of a wave start on one
-                        // tile and one sample chunk (coherent primary rays)
-                        const uint32_t tc = q >> 6;
-                        const uint32_t tile = new_tile;
-                        const uint32_t chunk = tc % P.n_chunks;
-                        const uint32_t tx = tile % P.tiles_x, ty = tile / P.tiles_x;
-                        const uint32_t px = tx * HJR_TILE + (q & 7u);
-                        const uint32_t py = ty * HJR_TILE + ((q >> 3) & 7u);
-                        if (px < P.width && py < P.height) {
-                            has_item = true; path_live = false;
-                            item = px | (py << 13) | (chunk << 26);
-                            s = chunk * P.chunk_spp;
-                            sumL = V1(0.0f); sumA = V1(0.0f); sumN = V1(0.0f);
-                        }
-                    } else dead = true;
-                }
-            }
-            if (__ballot(!dead) == 0ull) break; // a lane only dies with nothing pending
-        }
-
-        if (!inflight) {
-            if (has_item && !path_live) {
-                start_path(P, ps, HJR_PX, HJR_PY, s);
-                if (!fin_pending) ps.L = V1(0.0f); // while fin_pending, ps.L still belongs to the finished path
-                path_live = true; fresh = true;
-                // the new path's own roulette draw: throughput is (1,1,1), so russian_p = 1 > xi for every xi in [0,1) and
-                // thr / 1 == thr; only the stream position moves
-                ps.rng_depth += 1u;
-            }
-            tracing = has_item;
-        }
-
+        bounce_pre_trace<STATS, AOVS>(P, c, wr, !inflight, tracing, lc);
+        if (__ballot(!c.dead) == 0ull) break; // a lane only dies with nothing pending
         HJR_TICK(0)
 #ifdef HJR_TIMING
-        oc[0] += 1; oc[1] += __popcll(__ballot(tracing)); oc[2] += __popcll(__ballot(sh_valid));
+        oc[0] += 1; oc[1] += __popcll(__ballot(tracing)); oc[2] += __popcll(__ballot(c.sh_valid));
 #endif
         // ---- one fused traversal: pending shadow ray (TraceOcculution, rt.h:236-243) then closest-hit ray (RayTrace, rt.h:182-189)
         {
             Counters ca, cb; ca.box = ca.tri = cb.box = cb.tri = 0;
             const f3 cam_o = V(P.cam_pos[0], P.cam_pos[1], P.cam_pos[2]);
-            inflight = traverse_fused<STATS, WIDTH, BLOCK, ST, (LDSBVH ? HJR_CARRY_LDS : HJR_CARRY_MEM)>(nodes, tris, sh_valid, ps.ro, sh_d, sh_tmax, tracing, fresh ? cam_o : ps.ro, ps.rd, occluded, h, stack, ca, cb, inflight, tc);
-#ifdef HJR_TIMING
-            tk6 += ca.t_node; tk7 += ca.t_leaf;
-#endif
+            inflight = traverse_fused<STATS, WIDTH, BLOCK, ST, (LDSBVH ? HJR_CARRY_LDS : HJR_CARRY_MEM)>(nodes, tris, c.sh_valid, c.ps.ro, c.sh_d, c.sh_tmax, tracing, c.fresh ? cam_o : c.ps.ro, c.ps.rd, occluded, h, stack, ca, cb, inflight, tc);
             if (STATS) { // tests are counted round by round, rays when they are resolved
                 lc[5] += ca.box; lc[6] += ca.tri; lc[3] += cb.box; lc[4] += cb.tri;
-                if (!inflight) { if (sh_valid) lc[2] += 1; if (tracing) lc[1] += 1; }
+                if (!inflight) { if (c.sh_valid) lc[2] += 1; if (tracing) lc[1] += 1; }
             }
         }
         HJR_TICK(1)
 #ifdef HJR_TIMING
-        oc[7] += __popcll(__ballot(!inflight && (tracing || sh_valid)));
+        oc[3] += __popcll(__ballot(!inflight && (tracing || c.sh_valid)));
 #endif
-        if (inflight) continue;
-        if (sh_valid) { // `if (!light_shot.is_hit) LTE += ...` (rt.h:245-259), added to the path the shadow ray belongs to
-            if (!occluded) ps.L = ps.L + sh_contrib; // ps.L is the finished path's radiance while fin_pending
-            sh_valid = false;
-        }
-        if (fin_pending) {
-            finish_sample(ps.L);
-            ps.L = V1(0.0f); // from here on ps.L belongs to the path that was regenerated (or to nothing)
-            fin_pending = false;
-            if (write_pending) write_out();
-        }
-        HJR_TICKX(1)
-
-        if (tracing) {
-            it_cost++;
-            HitInfo prd;
-            hit_program<STATS, AOVS>(P, tris, mats, h, ps.rd, prd, lc);
-            HJR_TICKX(2)
-            if (AOVS && ps.depth == 0) { sumA = sumA + prd.surf.basecolor; sumN = sumN + prd.normal; } // rt.h:191-194
-            if (!prd.is_hit || prd.is_light) {
-                // NEE / MIS count emission only at depth 0 (rt.h:196-208, 318-330); Pathtrace always (rt.h:118-126)
-                if (INTEGRATOR == HJR_INTEGRATOR_PT_ || ps.depth == 0) ps.L = ps.L + ps.thr * prd.emission;
-                finish_sample(ps.L);
-                close_sample();
-                if (write_pending) write_out();
-            } else {
-                HJR_TICK(2)
-#ifdef HJR_TIMING
-                dg_shade = true; dg_ms = !prd.surf.is_specular && prd.surf.metallic > 0.5f; dg_glass = prd.surf.is_specular;
-#endif
-                CMJState st = path_rng(P, HJR_PX, HJR_PY, s, ps.rng_depth);
-                const Surface& sf = prd.surf;
-                f3 t, b;
-                const f3 n = prd.normal;
-                orthonormal_basis(n, t, b);
-                const f3 local_wo = world_to_local(-ps.rd, t, n, b);
-
-                if (INTEGRATOR != HJR_INTEGRATOR_PT_ && P.n_lights >= 1u) { // light_prim_count < 1: no contribution (UB in the reference)
-                    float light_pdf;
-                    f3 light_color, light_normal;
-                    const f3 light_position = light_sample(P, lights, st, light_pdf, light_normal, light_color);
-                    if (STATS) lc[8] += 1;
-                    const f3 so = prd.position;
-                    f3 sd;
-                    float light_distance;
-                    if (INTEGRATOR == HJR_INTEGRATOR_NEE_) { // rt.h:230-233
-                        sd = normalize(light_position - so);
-                        light_distance = length3(light_position - so);
-                    } else { // rt.h:352-354
-                        sd = light_position - so;
-                        light_distance = length3(sd);
-                        sd = normalize(sd);
-                    }
-                    // the contribution is fully determined here; only whether it is added depends on the shadow ray, which is
-                    // traced fused with the next closest-hit ray at the top of the next iteration
-                    const float cosine1 = absdot(n, sd);
-                    const float cosine2 = absdot(light_normal, -sd);
-                    const f3 local_wi = world_to_local(sd, t, n, b);
-                    const f3 bsdf = bsdf_eval(P, sf, local_wo, local_wi);
-                    const float G = cosine2 / (light_distance * light_distance);
-                    if (INTEGRATOR == HJR_INTEGRATOR_NEE_) {
-                        sh_contrib = (ps.thr * ((bsdf * G * cosine1) / light_pdf)) * light_color; // rt.h:258
-                    } else {
-                        const float pt_pdf = bsdf_pdf(sf, local_wo, local_wi) * G;
-                        const float mis_weight = light_pdf / (light_pdf + pt_pdf);
-                        sh_contrib = ((ps.thr * ((bsdf * G * cosine1) / light_pdf)) * mis_weight) * light_color; // rt.h:378
-                    }
-                    sh_d = sd; sh_tmax = light_distance - 0.001f; // origin = prd.position = ps.ro below
-                    // an exactly-zero contribution (every hit on the glass lobe, whose evaluateBSDF is 0) cannot change L whatever
-                    // the shadow ray returns (x + 0 == x): skip the trace.  A NaN contribution still goes through.
-                    sh_valid = !(sh_contrib.x == 0.0f && sh_contrib.y == 0.0f && sh_contrib.z == 0.0f);
-                }
-
-                if (INTEGRATOR == HJR_INTEGRATOR_MIS_) { // BSDF-sampled light hit, rt.h:383-420
-                    // MIS adds this term AFTER the NEE term of the same bounce (rt.h:378 then :414/:418); the NEE term is still
-                    // pending, so resolve its shadow ray now to keep the order of the float additions
-                    if (sh_valid) {
-                        Hit shh;
-                        Counters c; c.box = 0; c.tri = 0;
-                        const bool occ = traverse<true, STATS, WIDTH, BLOCK, ST>(nodes, tris, prd.position, sh_d, 0.001f, sh_tmax, shh, stack, c);
-                        if (STATS) { lc[2] += 1; lc[5] += c.box; lc[6] += c.tri; }
-                        if (!occ) ps.L = ps.L + sh_contrib;
-                        sh_valid = false;
-                    }
-                    float pt_pdf = 1.0f; // uninitialised in the reference when msGGX returns early; defined as 1
-                    f3 local_wi = V(0.0f, 1.0f, 0.0f);
-                    const f3 brdf = bsdf_sample(P, sf, local_wo, local_wi, pt_pdf, st);
-                    const f3 wi = local_to_world(local_wi, t, n, b);
-                    const float cosine1 = absdot(wi, n);
-                    HitInfo lh;
-                    ray_trace<STATS, AOVS, WIDTH, BLOCK, ST>(P, nodes, tris, mats, prd.position, wi, lh, stack, lc);
-                    if (lh.is_hit) {
-                        if (lh.is_light) {
-                            const float cosine2 = absdot(-wi, lh.normal);
-                            const float light_distance = length3(lh.position - prd.position);
-                            const float invG = light_distance * light_distance / cosine2;
-                            // getLightPDF(prim, inst) (light_sample.h:77-92): 1 / (area * light_prim_count), area from the light
-                            // table's world vertices (== transform_position of the same object vertices); the table row of an
-                            // emissive triangle is found by its global prim id (l4.w)
-                            float lp = 0.0f;
-                            if (!sf.is_specular) {
-                                for (uint32_t li = 0; li < P.n_lights; li++) {
-                                    const float4* Lr = lights + li * HJR_LIGHT_F4;
-                                    if (f2bits(Lr[4].w) == lh.prim) {
-                                        const float4 a0 = Lr[0], a1 = Lr[1], a2 = Lr[2];
-                                        const f3 c = cross(V(a1.x, a1.y, a1.z) - V(a0.x, a0.y, a0.z), V(a2.x, a2.y, a2.z) - V(a0.x, a0.y, a0.z));
-                                        const float area = length3(c) * 0.5f;
-                                        lp = 1.0f / (area * P.n_lights);
-                                        break;
-                                    }
-                                }
-                                lp = lp * invG;
-                            }
-                            const float mis_weight = pt_pdf / (pt_pdf + lp);
-                            ps.L = ps.L + ((((ps.thr * mis_weight) * cosine1) * lh.emission) * brdf) / pt_pdf; // rt.h:414
-                        }
-                    } else {
-                        ps.L = ps.L + (((ps.thr * brdf) * cosine1) * lh.emission) / pt_pdf; // rt.h:418
-                    }
-                }
-
-                HJR_TICK(3)
-                float pdf = 1.0f;
-                f3 local_wi = V(0.0f, 1.0f, 0.0f);
-                if (INTEGRATOR != HJR_INTEGRATOR_PT_) (void)cmj_2d(st); // drawn and discarded by the reference (rt.h:266, 426)
-                const f3 bsdf = bsdf_sample(P, sf, local_wo, local_wi, pdf, st);
-                const f3 wi = local_to_world(local_wi, t, n, b);
-                ps.thr = ps.thr * ((bsdf * fabsf(dot(wi, n))) / pdf); // rt.h:274
-                ps.ro = prd.position;
-                ps.rd = wi;
-                fresh = false;
-                ps.rng_depth = st.depth;
-                ps.depth++;
-                if (ps.depth == 10) { // MaxDepth (rt.h:166): the path is over; its last shadow ray, if any, is still pending
-                    if (sh_valid) { fin_pending = true; close_sample(); }
-                    else {
-                        finish_sample(ps.L);
-                        ps.L = V1(0.0f);
-                        close_sample();
-                        if (write_pending) write_out();
-                    }
-                }
-                HJR_TICK(4)
-            }
-        }
-        HJR_TICK(5)
+        if (!inflight) bounce_post_trace<INTEGRATOR, STATS, AOVS, WIDTH, BLOCK, ST>(P, nodes, tris, mats, lights, c, tracing, occluded, h, stack, lc);
+        HJR_TICK(2)
     }
 #ifdef HJR_TIMING
-    if (lane == 0) { for (int i = 0; i < 6; i++) atomicAdd(&P.stats[HJR_NSTAT + i], tk[i]); atomicAdd(&P.stats[HJR_NSTAT + 6], tk6); atomicAdd(&P.stats[HJR_NSTAT + 7], tk7); }
-    if (__ffsll((long long)__ballot(true)) - 1 == (int)lane) { for (int i = 0; i < 6; i++) atomicAdd(&P.stats[HJR_NSTAT + 8 + i], oc[i]); atomicAdd(&P.stats[HJR_NSTAT + 18], oc[6]); atomicAdd(&P.stats[HJR_NSTAT + 19], oc[7]); }
-    if (lane == 0) for (int i = 0; i < 4; i++) atomicAdd(&P.stats[HJR_NSTAT + 14 + i], tx[i]);
+    if (lane == 0) for (int i = 0; i < 3; i++) atomicAdd(&P.stats[HJR_NSTAT + i], tk[i]);
+    if (__ffsll((long long)__ballot(true)) - 1 == (int)lane) for (int i = 0; i < 4; i++) atomicAdd(&P.stats[HJR_NSTAT + 3 + i], oc[i]);
 #endif
 
     if (STATS) {
@@ -685,7 +707,7 @@ __global__ void __launch_bounds__(256) hjr_finalize_kernel(const KParams P)
         const uint32_t tile = (uint32_t)(sl >> 6) * P.world + P.rank;
         const uint32_t x = (tile % P.tiles_x) * HJR_TILE + ((uint32_t)sl & 7u), y = (tile / P.tiles_x) * HJR_TILE + (((uint32_t)sl >> 3) & 7u);
         if (x >= P.width || y >= P.height) continue;
-        const size_t pix = (size_t)y * P.width + x;
+        const size_t pix = P.packed ? sl : (size_t)y * P.width + x;
         float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f), b = a, c = a;
         for (uint32_t k = 0; k < P.n_chunks; k++) {
             const float4 v = P.part_color[(size_t)k * n_slots + sl];
@@ -697,4 +719,22 @@ __global__ void __launch_bounds__(256) hjr_finalize_kernel(const KParams P)
         if (P.aov_albedo) P.aov_albedo[pix] = make_float4(b.x * inv_spp, b.y * inv_spp, b.z * inv_spp, 1.0f);
         if (P.aov_normal) P.aov_normal[pix] = make_float4(c.x * inv_spp, c.y * inv_spp, c.z * inv_spp, 1.0f);
     }
+}
+
+// ---- tile pack / unpack: the multi-GPU exchange moves only owned tiles ([owned tile][64] float4)
+__global__ void __launch_bounds__(256) hjr_pack_tiles_kernel(const float4* frame, float4* packed, uint32_t width, uint32_t height, uint32_t tiles_x, uint32_t n_owned, uint32_t rank, uint32_t world)
+{
+    const size_t sl = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (sl >= (size_t)n_owned * 64u) return;
+    const uint32_t tile = (uint32_t)(sl >> 6) * world + rank;
+    const uint32_t x = (tile % tiles_x) * HJR_TILE + ((uint32_t)sl & 7u), y = (tile / tiles_x) * HJR_TILE + (((uint32_t)sl >> 3) & 7u);
+    packed[sl] = (x < width && y < height) ? frame[(size_t)y * width + x] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+__global__ void __launch_bounds__(256) hjr_unpack_tiles_kernel(const float4* packed, float4* frame, uint32_t width, uint32_t height, uint32_t tiles_x, uint32_t n_owned, uint32_t rank, uint32_t world)
+{
+    const size_t sl = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (sl >= (size_t)n_owned * 64u) return;
+    const uint32_t tile = (uint32_t)(sl >> 6) * world + rank;
+    const uint32_t x = (tile % tiles_x) * HJR_TILE + ((uint32_t)sl & 7u), y = (tile / tiles_x) * HJR_TILE + (((uint32_t)sl >> 3) & 7u);
+    if (x < width && y < height) frame[(size_t)y * width + x] = packed[sl];
 }

@@ -29,6 +29,7 @@ struct KParams {
     uint32_t width, height, spp, frame, seed, integrator;
     uint32_t tiles_x, n_owned_items; // items = owned tiles * n_chunks * 64
     uint32_t rank, world;
+    uint32_t packed;                 // HJR_FLAG_PACKED: the AOV buffers hold this rank's tiles only, [owned tile][64] float4
     uint32_t chunk_spp, n_chunks;    // samples per work item, work items per pixel (hjr_chunking)
     uint32_t n_node_f4, n_tri_f4;    // float4 counts of nodes[] / tri_geom[] (LDS staging)
     uint32_t n_mat_f4, n_light_f4;   // float4 counts of materials[] / lights[] (staged behind the triangles in the LDS variant)
@@ -45,7 +46,10 @@ struct KParams {
     uint32_t cost_div;               // 64 * spp: rays per tile at one ray per sample
     uint32_t spill_stride;           // lanes in the grid
     uint32_t stack_lds_entries;      // memory-path kernels: stack entries per lane kept in LDS (the rest overflow to stack_spill)
-    float4* part_color;              // [n_chunks][height][width] chunk sums when n_chunks > 1
+    float4* wf_ctx;                  // wavefront kernel: context planes, [plane][workgroup][wf_cap] float4 (hjr_wavefront.hip.h)
+    uint32_t wf_cap;                 // contexts per workgroup (power of two, <= 32768: ids travel as uint16 + 1)
+    uint32_t wf_plane_stride;        // contexts of all workgroups = grid x wf_cap
+    float4* part_color;              // [n_chunks][owned tile][64] chunk sums when n_chunks > 1
     float4* part_albedo;
     float4* part_normal;
     float cam_pos[3], cam_dir[3], cam_up[3], cam_right[3];

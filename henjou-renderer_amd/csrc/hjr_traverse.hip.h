@@ -6,9 +6,6 @@
 // ------------------------------------------------------------------ traversal: replaces optixTrace (kernel/rt.h:15-69) + RT cores
 struct Counters {
     uint32_t box, tri;
-#ifdef HJR_TIMING
-    unsigned long long t_node, t_leaf;
-#endif
 };
 
 HD float dotf(f3 a, f3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
@@ -249,9 +246,6 @@ HD bool traverse_fused(const float4* nodes, const float4* tris, const bool a_val
     f3 d = (phase == 0) ? ad : bd;
     BoxRay R = box_ray(o, d);
     const int n_start = CARRY > 0 ? __popcll(__ballot(phase < 2)) : 0;
-#ifdef HJR_TIMING
-    unsigned long long t_node = 0, t_leaf = 0, t_last = __builtin_amdgcn_s_memtime();
-#endif
     for (;;) {
         if (CARRY > 0) {
             const int n_act = __popcll(__ballot(phase < 2));
@@ -264,9 +258,6 @@ HD bool traverse_fused(const float4* nodes, const float4* tris, const bool a_val
             const uint32_t nb = node_step<WIDTH, BLOCK, ST>(nodes, cur, R, tmin, tfar, stack, sp);
             if (STATS) { if (phase == 0) ca.box += nb; else cb.box += nb; }
         }
-#ifdef HJR_TIMING
-        { __builtin_amdgcn_sched_barrier(0); unsigned long long now_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); t_node += now_ - t_last; t_last = now_; }
-#endif
         // ... then all lanes test their leaf's triangles together
         bool done = (cur == HJR_TRAV_DONE);
         if (!done) {
@@ -299,13 +290,7 @@ HD bool traverse_fused(const float4* nodes, const float4* tris, const bool a_val
                 sp = 0; cur = 0;
             } else { phase = 2; cur = HJR_TRAV_DONE; }
         }
-#ifdef HJR_TIMING
-        { __builtin_amdgcn_sched_barrier(0); unsigned long long now_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); t_leaf += now_ - t_last; t_last = now_; }
-#endif
     } }
-#ifdef HJR_TIMING
-    ca.t_node = t_node; ca.t_leaf = t_leaf;
-#endif
     if (CARRY > 0) { tc.phase = phase; tc.sp = sp; tc.cur = cur; return phase < 2; }
     return false;
 }

@@ -1,0 +1,413 @@
+// Workgroup-local wavefront form of the Henjou hot path (gfx950): the same per-lane bounce code as the megakernel
+// (hjr_kernel.hip.h: bounce_pre_trace / bounce_post_trace), re-scheduled so that a wavefront only ever runs lanes that need the
+// same thing.
+//
+// Why: in the megakernel a lane owns its path from the first to the last bounce, so each wave executes the union of what its 64
+// lanes need — rays of very different length in one traversal loop, three material classes in one shading pass.  rocprofv3 on the
+// bundled scene: 35 % of the VALU lanes do useful work while VALU issue is saturated (profiles/r02_*).  Here the 16 waves of the
+// one workgroup per CU share a pool of `wf_cap` path contexts (LaneCtx, parked in HBM / Infinity Cache between stages: 128 bytes
+// per context, the pool of a CU is a few hundred KB) and take work in batches from five queues of 16-bit context ids in LDS:
+//   * queue 0, TRACE: contexts with rays to trace (the pending NEE shadow ray of the bounce shaded last + the next closest-hit
+//     ray, as in the megakernel's fused traversal).  A wave traces 64 of them; lanes that finish hand their result over and take
+//     the next context as soon as HJR_WF_REFILL lanes are waiting, so ray-length variance no longer idles lanes;
+//   * queues 1..4, SHADE by the class of what the closest-hit ray found (path ends: miss / light; Disney; multiple-scattering
+//     GGX; glass).  A wave takes up to 64 contexts of ONE class, runs bounce_post_trace + bounce_pre_trace on them (wave-uniform
+//     branches in practice) and queues them for TRACE again.  The class only decides which lanes run together, never what a lane
+//     computes: every pixel is bit-identical to the megakernel's and the oracle's.
+// Contexts regenerate in place (a context whose path ends starts the next sample of its item, then the next item of the global
+// queue), so the pool stays full until the frame runs out of work; a context with nothing left is retired, and the waves leave
+// when the live count reaches zero.  All synchronisation is workgroup-local (LDS atomics + workgroup-scope fences): one
+// workgroup is one CU, no cross-CU protocol is involved.
+#pragma once
+#include "hjr_kernel.hip.h"
+
+#ifndef HJR_WF_REFILL
+#define HJR_WF_REFILL 16 /* trace stage: lanes waiting (finished or empty) before the wave stops to report / refill */
+#endif
+#ifndef HJR_WF_TRACE_MIN
+#define HJR_WF_TRACE_MIN 32 /* scheduler: a TRACE batch is preferred over a partial SHADE batch from this many queued rays on */
+#endif
+#define HJR_WF_QUEUES 5
+#define HJR_WF_PLANES_LEAN 8
+#define HJR_WF_PLANES_FULL 10
+
+// queue header in LDS (after the scene tables); rings of uint16 ids follow it
+struct WfShared {
+    uint32_t head[HJR_WF_QUEUES];  // next ring position to take
+    uint32_t tail[HJR_WF_QUEUES];  // next ring position to reserve
+    uint32_t count[HJR_WF_QUEUES]; // committed entries not yet claimed
+    uint32_t live;                 // contexts not yet retired
+    uint32_t items_held;           // work items sitting unassigned in the private ranges of this workgroup's waves (WaveRange::held)
+};
+
+// context flags word (plane 1 .w)
+#define WF_HAS_ITEM 1u
+#define WF_DEAD 2u
+#define WF_PATH_LIVE 4u
+#define WF_FIN_PENDING 8u
+#define WF_WRITE_PENDING 16u
+#define WF_SH_VALID 32u
+#define WF_FRESH 64u
+#define WF_TRACING 128u /* the context has a closest-hit ray in this round (bounce_pre_trace's `tracing`) */
+#define WF_MISS 0x7fffffffu
+
+#ifdef HJR_WF_WATCHDOG
+// diagnostic build: every loop of the kernel gives up 1.5 s after the workgroup started (100 MHz real-time counter) and records where
+__device__ unsigned int wf_watchdog_word;
+__device__ unsigned int wf_where[8]; // [1] take, [2] push wait, [3] scheduler wait, [4] trace loop, [5] pop CAS
+__shared__ unsigned long long wf_t0;
+HD bool wf_expired(int where)
+{
+    if (__builtin_amdgcn_s_memrealtime() - wf_t0 < 150000000ull) return false;
+    atomicAdd(&wf_where[where], 1u);
+    return true;
+}
+#define WF_EXPIRED(w) wf_expired(w)
+#else
+#define WF_EXPIRED(w) false
+#endif
+
+// ---- queue operations.  Every one is called by all 64 lanes of a wave at a wave-uniform point.
+// Claims up to `want` committed entries of queue q: returns how many (wave-uniform) and the first ring position.
+HD uint32_t wf_pop(WfShared* Q, int q, uint32_t want, uint32_t& start)
+{
+    uint32_t got = 0, st = 0;
+    if ((threadIdx.x & 63u) == 0u && want) {
+        uint32_t c = __hip_atomic_load(&Q->count[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        while (c != 0u) {
+            if (WF_EXPIRED(5)) break;
+            const uint32_t take = c < want ? c : want;
+            const uint32_t old = atomicCAS(&Q->count[q], c, c - take);
+            if (old == c) { got = take; st = atomicAdd(&Q->head[q], take); break; }
+            c = old;
+        }
+    }
+    start = (uint32_t)__builtin_amdgcn_readfirstlane((int)st);
+    got = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
+    if (got) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    return got;
+}
+// The id at ring position pos of queue q.  A claimed position may belong to a producer that has reserved it but not written it
+// yet (commits of different producers can overtake each other): wait for the non-zero marker, then free the slot.
+HD uint32_t wf_take(uint16_t* rings, int q, uint32_t pos, uint32_t cap)
+{
+    volatile uint16_t* slot = rings + (size_t)q * cap + (pos & (cap - 1u));
+    // Each lane frees its slot in the loop iteration after the one that read it, i.e. while other lanes of the wave may still be
+    // waiting for theirs: a clear that waited for the whole wave could land after the slot's next producer has reused it (lost
+    // entry), or keep that producer waiting for a wave that is itself waiting for a producer (deadlock).
+    uint32_t v = 0u;
+    bool cleared = false;
+#ifdef HJR_WF_WATCHDOG
+    uint32_t spins = 0;
+#endif
+    while (!cleared) {
+        if (v == 0u) {
+            v = *slot;
+#ifdef HJR_WF_WATCHDOG
+            if (v == 0u && (++spins & 1023u) == 0u && WF_EXPIRED(1)) { wf_watchdog_word = 0x80000000u | ((uint32_t)q << 24) | (pos & 0xffffffu); v = 1u; }
+#endif
+        } else { *slot = 0; cleared = true; }
+    }
+    return v - 1u;
+}
+// Appends the ids of the lanes with `flag` to queue q.  Everything the wave wrote before (context planes in memory, ring slots in
+// LDS) is made visible to the workgroup before the entries are committed.
+HD void wf_push(WfShared* Q, uint16_t* rings, int q, bool flag, uint32_t id, uint32_t cap)
+{
+    const unsigned long long m = __ballot(flag);
+    if (m == 0ull) return;
+    const uint32_t n = (uint32_t)__popcll(m);
+    const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    uint32_t pos = 0;
+    if ((threadIdx.x & 63u) == 0u) pos = atomicAdd(&Q->tail[q], n);
+    pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos);
+    if (flag) {
+        // a ring holds at most wf_cap ids, so the reserved slot is free unless its previous taker has claimed it but not read it yet
+        // (possible only when the whole pool passes through one queue meanwhile): wait for the taker's clear before reusing it
+        volatile uint16_t* slot = rings + (size_t)q * cap + ((pos + prefix) & (cap - 1u));
+        while (*slot != 0) { if (WF_EXPIRED(2)) break; }
+        *slot = (uint16_t)(id + 1u);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if ((threadIdx.x & 63u) == 0u) atomicAdd(&Q->count[q], n);
+}
+
+// ---- context planes: float4 arrays of `stride` contexts each (all workgroups), this workgroup's contexts at [0, cap) of `ctx`
+//   0: ro.xyz rd.x   1: rd.yz sh_tmax flags   2: sh_d.xyz item   3: thr.xyz s   4: L.xyz it_cost   5: sumL.xyz (depth | rng_depth << 8)
+//   6: sh_contrib.xyz -   7: hit t b1 b2 (k | occluded << 31)   8: sumA.xyz -   9: sumN.xyz -      (8, 9: AOVS variant only)
+template <bool AOVS> HD void wf_store_ctx(float4* ctx, size_t stride, uint32_t id, const LaneCtx& c, bool tracing)
+{
+    const uint32_t flags = (c.has_item ? WF_HAS_ITEM : 0u) | (c.dead ? WF_DEAD : 0u) | (c.path_live ? WF_PATH_LIVE : 0u) | (c.fin_pending ? WF_FIN_PENDING : 0u) |
+                           (c.write_pending ? WF_WRITE_PENDING : 0u) | (c.sh_valid ? WF_SH_VALID : 0u) | (c.fresh ? WF_FRESH : 0u) | (tracing ? WF_TRACING : 0u);
+    float4* p = ctx + id;
+    p[0 * stride] = make_float4(c.ps.ro.x, c.ps.ro.y, c.ps.ro.z, c.ps.rd.x);
+    p[1 * stride] = make_float4(c.ps.rd.y, c.ps.rd.z, c.sh_tmax, bits2f(flags));
+    p[2 * stride] = make_float4(c.sh_d.x, c.sh_d.y, c.sh_d.z, bits2f(c.item));
+    p[3 * stride] = make_float4(c.ps.thr.x, c.ps.thr.y, c.ps.thr.z, bits2f(c.s));
+    p[4 * stride] = make_float4(c.ps.L.x, c.ps.L.y, c.ps.L.z, bits2f(c.it_cost));
+    p[5 * stride] = make_float4(c.sumL.x, c.sumL.y, c.sumL.z, bits2f((uint32_t)c.ps.depth | (c.ps.rng_depth << 8)));
+    p[6 * stride] = make_float4(c.sh_contrib.x, c.sh_contrib.y, c.sh_contrib.z, 0.0f);
+    if (AOVS) {
+        p[8 * stride] = make_float4(c.sumA.x, c.sumA.y, c.sumA.z, 0.0f);
+        p[9 * stride] = make_float4(c.sumN.x, c.sumN.y, c.sumN.z, 0.0f);
+    }
+}
+template <bool AOVS> HD void wf_load_ctx(const float4* ctx, size_t stride, uint32_t id, LaneCtx& c, bool& tracing, float4& hitrec)
+{
+    const float4* p = ctx + id;
+    const float4 a = p[0 * stride], b = p[1 * stride], d = p[2 * stride], e = p[3 * stride], f = p[4 * stride], g = p[5 * stride], h = p[6 * stride];
+    hitrec = p[7 * stride];
+    const uint32_t flags = f2bits(b.w);
+    c.has_item = flags & WF_HAS_ITEM; c.dead = flags & WF_DEAD; c.path_live = flags & WF_PATH_LIVE; c.fin_pending = flags & WF_FIN_PENDING;
+    c.write_pending = flags & WF_WRITE_PENDING; c.sh_valid = flags & WF_SH_VALID; c.fresh = flags & WF_FRESH;
+    tracing = flags & WF_TRACING;
+    c.ps.ro = V(a.x, a.y, a.z); c.ps.rd = V(a.w, b.x, b.y); c.sh_tmax = b.z;
+    c.sh_d = V(d.x, d.y, d.z); c.item = f2bits(d.w);
+    c.ps.thr = V(e.x, e.y, e.z); c.s = f2bits(e.w);
+    c.ps.L = V(f.x, f.y, f.z); c.it_cost = f2bits(f.w);
+    c.sumL = V(g.x, g.y, g.z); c.ps.depth = (int)(f2bits(g.w) & 0xffu); c.ps.rng_depth = f2bits(g.w) >> 8;
+    c.sh_contrib = V(h.x, h.y, h.z);
+    if (AOVS) {
+        const float4 sa = p[8 * stride], sn = p[9 * stride];
+        c.sumA = V(sa.x, sa.y, sa.z); c.sumN = V(sn.x, sn.y, sn.z);
+    } else { c.sumA = V1(0.0f); c.sumN = V1(0.0f); }
+}
+
+// ---- TRACE stage: the fused two-ray traversal of the megakernel (hjr_traverse.hip.h::traverse_fused: shadow ray, then the
+// closest-hit ray, "while-while") with lane-level turnover.  phase: 0 shadow ray, 1 closest-hit ray, 2 empty, 3 finished (result
+// not handed over yet).  Returns when no lane has a ray and the TRACE queue is empty.
+template <bool STATS, int WIDTH, int BLOCK, typename ST>
+HD void wf_trace_stage(const KParams& P, WfShared* Q, uint16_t* rings, const float4* nodes, const float4* tris, const float4* mats, float4* ctx, ST& stack, unsigned long long* lc)
+{
+    const uint32_t cap = P.wf_cap;
+    const size_t stride = P.wf_plane_stride;
+    const float tmin = 0.001f;
+    const f3 cam_o = V(P.cam_pos[0], P.cam_pos[1], P.cam_pos[2]);
+    int phase = 2, sp = 0;
+    uint32_t cur = HJR_TRAV_DONE, id = 0;
+    f3 o = V1(0.0f), d = V(1.0f, 0.0f, 0.0f), ro = V1(0.0f), db = V1(0.0f);
+    float a_tmax = 0.0f;
+    bool b_valid = false, fresh = false, occluded = false;
+    Hit hit; hit.prim = 0xffffffffu; hit.t = 1e16f; hit.k = 0; hit.b1 = hit.b2 = 0.0f;
+    BoxRay R = box_ray(o, d);
+    for (;;) {
+        if (WF_EXPIRED(4)) return;
+        const uint32_t n_wait = (uint32_t)__popcll(__ballot(phase >= 2));
+        if (n_wait >= (uint32_t)HJR_WF_REFILL || n_wait == 64u) {
+            // ---- hand the finished rays over: hit record -> context plane 7, context id -> the SHADE queue of what was hit
+            const bool fin = phase == 3;
+            if (__ballot(fin)) {
+                uint32_t cls = 0;
+                if (fin) {
+                    uint32_t kk = WF_MISS;
+                    if (hit.prim != 0xffffffffu) {
+                        kk = hit.k;
+                        const float4* m = mats + f2bits(tris[hit.k * HJR_TRI_F4 + 2].z) * HJR_MAT_F4;
+                        const float4 m0 = m[0], m3 = m[3];
+                        cls = f2bits(m3.x) != 0 ? 0u : (f2bits(m3.y) != 0 ? 3u : (m0.w > 0.5f ? 2u : 1u)); // light | glass | metallic (msGGX) | Disney
+                    }
+                    ctx[7 * stride + id] = make_float4(hit.t, hit.b1, hit.b2, bits2f(kk | (occluded ? 0x80000000u : 0u)));
+                }
+                for (uint32_t q = 0; q < 4u; q++) wf_push(Q, rings, 1 + (int)q, fin && cls == q, id, cap);
+                if (fin) phase = 2;
+            }
+            // ---- refill the empty lanes from the TRACE queue
+            const unsigned long long m_idle = __ballot(phase == 2);
+            uint32_t start = 0;
+            const uint32_t got = wf_pop(Q, 0, (uint32_t)__popcll(m_idle), start);
+            if (got) {
+                const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(m_idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_idle, 0u));
+                if (phase == 2 && prefix < got) {
+                    id = wf_take(rings, 0, start + prefix, cap);
+                    const float4 p0 = ctx[0 * stride + id], p1 = ctx[1 * stride + id], p2 = ctx[2 * stride + id];
+                    const uint32_t flags = f2bits(p1.w);
+                    ro = V(p0.x, p0.y, p0.z); db = V(p0.w, p1.x, p1.y); a_tmax = p1.z;
+                    b_valid = flags & WF_TRACING; fresh = flags & WF_FRESH;
+                    occluded = false;
+                    hit.prim = 0xffffffffu; hit.t = 1e16f;
+                    phase = (flags & WF_SH_VALID) ? 0 : 1; // a queued context has at least one of the two rays
+                    o = (phase == 0 || !fresh) ? ro : cam_o;
+                    d = (phase == 0) ? V(p2.x, p2.y, p2.z) : db;
+                    R = box_ray(o, d);
+                    sp = 0; cur = 0;
+                }
+            }
+            if (__ballot(phase < 2) == 0ull) return;
+        }
+        if (phase < 2) {
+            while (!(cur & HJR_LEAF_FLAG)) { // every lane first descends through inner nodes until it holds a leaf (or is out of work) ...
+                const float tfar = (phase == 0) ? a_tmax : hit.t;
+                const uint32_t nb = node_step<WIDTH, BLOCK, ST>(nodes, cur, R, tmin, tfar, stack, sp);
+                if (STATS) { if (phase == 0) lc[5] += nb; else lc[3] += nb; }
+            }
+            bool done = (cur == HJR_TRAV_DONE); // ... then all lanes test their leaf's triangles together
+            if (!done) {
+                const uint32_t first = cur & 0x07ffffffu, count = (cur >> 27) & 15u;
+                const float tri_tmax = (phase == 0) ? a_tmax : 1e16f;
+                for (uint32_t i = 0; i < count; i++) {
+                    const float4* g = tris + (first + i) * HJR_TRI_F4;
+                    const float4 g0 = g[0], g1 = g[1], g2 = g[2];
+                    float t, b1, b2;
+                    if (STATS) { if (phase == 0) lc[6] += 1; else lc[4] += 1; }
+                    if (ray_tri(V(g0.x, g0.y, g0.z), V(g0.w, g1.x, g1.y), V(g1.z, g1.w, g2.x), o, d, tmin, tri_tmax, t, b1, b2)) {
+                        if (phase == 0) { occluded = true; done = true; break; }
+                        const uint32_t prim = f2bits(g2.y);
+                        // order-independent closest-hit rule: smaller t wins; equal t -> smaller global prim id
+                        if (hit.prim == 0xffffffffu || t < hit.t || (t == hit.t && prim < hit.prim)) {
+                            hit.t = t; hit.b1 = b1; hit.b2 = b2; hit.k = first + i; hit.prim = prim;
+                        }
+                    }
+                }
+                if (!done) {
+                    if (sp > 0) { sp--; cur = stack.get(sp); }
+                    else done = true;
+                }
+            }
+            if (done) {
+                if (STATS) { if (phase == 0) lc[2] += 1; else lc[1] += 1; }
+                if (phase == 0 && b_valid) { // this lane's shadow ray is resolved: start its closest-hit ray right away
+                    phase = 1;
+                    o = fresh ? cam_o : ro; d = db;
+                    R = box_ray(o, d);
+                    sp = 0; cur = 0;
+                } else { phase = 3; cur = HJR_TRAV_DONE; }
+            }
+        }
+    }
+}
+
+// ---- SHADE stage: up to 64 contexts of one class: second half of the bounce just traced, first half of the next one
+template <int INTEGRATOR, bool STATS, bool AOVS, int WIDTH, int BLOCK, typename ST>
+HD void wf_shade_stage(const KParams& P, WfShared* Q, uint16_t* rings, int q, const float4* nodes, const float4* tris, const float4* mats, const float4* lights,
+                       float4* ctx, WaveRange& wr, ST& stack, unsigned long long* lc)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t cap = P.wf_cap;
+    const size_t stride = P.wf_plane_stride;
+    uint32_t start = 0;
+    const uint32_t got = wf_pop(Q, q, 64u, start);
+    if (got == 0u) return;
+    const bool have = lane < got;
+    LaneCtx c;
+    ctx_reset(c);
+    c.dead = true; // lanes without a context take no part in the refill
+    bool tracing = false;
+    uint32_t id = 0;
+    if (have) {
+        id = wf_take(rings, q, start + lane, cap);
+        float4 hr;
+        wf_load_ctx<AOVS>(ctx, stride, id, c, tracing, hr);
+        const uint32_t kk = f2bits(hr.w);
+        Hit h;
+        h.t = hr.x; h.b1 = hr.y; h.b2 = hr.z; h.k = kk & 0x7fffffffu;
+        h.prim = (h.k == WF_MISS) ? 0xffffffffu : f2bits(tris[h.k * HJR_TRI_F4 + 2].y);
+        bounce_post_trace<INTEGRATOR, STATS, AOVS, WIDTH, BLOCK, ST>(P, nodes, tris, mats, lights, c, tracing, (kk >> 31) != 0u, h, stack, lc);
+    }
+    tracing = false;
+    bounce_pre_trace<STATS, AOVS>(P, c, wr, have, tracing, lc);
+    const bool again = have && (tracing || c.sh_valid);
+    // no ray, not dead: the item it took lies outside a ragged frame edge; it takes the next one in another pass (class "path ends")
+    const bool retry = have && !again && !c.dead;
+    if (again || retry) wf_store_ctx<AOVS>(ctx, stride, id, c, tracing);
+    wf_push(Q, rings, 0, again, id, cap);
+    wf_push(Q, rings, 1, retry, id, cap);
+    const uint32_t retired = (uint32_t)__popcll(__ballot(have && !again && !retry)); // no ray and no item left: the context is finished
+    if (retired && lane == 0u) atomicSub(&Q->live, retired);
+}
+
+// Dynamic LDS: [traversal stacks][scene tables when LDSBVH][WfShared][rings: HJR_WF_QUEUES x wf_cap uint16]
+template <int INTEGRATOR, bool STATS, int BLOCK, bool LDSBVH, bool STACK16, int WIDTH, bool AOVS>
+__global__ void __launch_bounds__(BLOCK, 1) hjr_wavefront_kernel(const KParams P)
+{
+    typedef typename std::conditional<STACK16, uint16_t, uint32_t>::type SE;
+    typedef LaneStack<SE, BLOCK, !LDSBVH, STATS> ST;
+    ST stack;
+    stack.n_over = 0;
+    stack.lds = reinterpret_cast<SE*>(hjr_smem) + threadIdx.x;
+    stack.spill = P.stack_spill + (blockIdx.x * BLOCK + threadIdx.x);
+    stack.spill_stride = P.spill_stride;
+    stack.lds_n = (int)P.stack_lds_entries;
+    const uint32_t lane = threadIdx.x & 63u;
+    const float4* nodes = P.nodes;
+    const float4* tris = P.tri_geom;
+    const float4* mats = P.materials;
+    const float4* lights = P.lights;
+    const uint32_t stack_entries = LDSBVH ? P.stack_depth : P.stack_lds_entries;
+    float4* after_stacks = hjr_smem + (BLOCK * stack_entries * (uint32_t)sizeof(SE) + 15u) / 16u;
+    const uint32_t scene_f4 = LDSBVH ? (P.n_node_f4 + P.n_tri_f4 + P.n_mat_f4 + P.n_light_f4) : 0u;
+    WfShared* Q = reinterpret_cast<WfShared*>(after_stacks + scene_f4);
+    uint16_t* rings = reinterpret_cast<uint16_t*>(after_stacks + scene_f4 + 5); // the header takes 80 bytes
+    const uint32_t cap = P.wf_cap;
+    // all contexts start in SHADE queue 1 (class "path ends") with every flag clear: their first pass does nothing but take an item
+    for (uint32_t i = threadIdx.x; i < HJR_WF_QUEUES * cap; i += BLOCK) rings[i] = (i >= cap && i < 2u * cap) ? (uint16_t)(i - cap + 1u) : (uint16_t)0;
+    if (threadIdx.x < HJR_WF_QUEUES) { Q->head[threadIdx.x] = 0u; Q->tail[threadIdx.x] = threadIdx.x == 1u ? cap : 0u; Q->count[threadIdx.x] = threadIdx.x == 1u ? cap : 0u; }
+    if (threadIdx.x == 0u) { Q->live = cap; Q->items_held = 0u; }
+#ifdef HJR_WF_WATCHDOG
+    if (threadIdx.x == 0u) wf_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    float4* ctx = P.wf_ctx + (size_t)blockIdx.x * cap;
+    {
+        const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        const int planes = AOVS ? HJR_WF_PLANES_FULL : HJR_WF_PLANES_LEAN;
+        for (uint32_t i = threadIdx.x; i < cap; i += BLOCK)
+            for (int pl = 0; pl < planes; pl++) ctx[(size_t)pl * P.wf_plane_stride + i] = pl == 1 ? make_float4(0.0f, 0.0f, 0.0f, bits2f(WF_FRESH)) : z;
+    }
+    if (LDSBVH) stage_scene_in_lds<SE, BLOCK>(P, after_stacks, nodes, tris, mats, lights); // ends with a barrier
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+    unsigned long long lc[HJR_NSTAT];
+    if (STATS) for (int i = 0; i < HJR_NSTAT; i++) lc[i] = 0;
+    WaveRange wr; wr.next = wr.end = 0u; wr.exhausted = false; wr.held = &Q->items_held;
+#ifdef HJR_WF_WATCHDOG
+    uint32_t idle_spins = 0;
+#endif
+
+    for (;;) {
+        // wave-uniform choice of the next batch: a full SHADE batch first (largest class), then TRACE, then whatever is there
+        uint32_t pick = 7u; // 0 trace, 1..4 shade class, 6 leave, 7 wait
+        if (lane == 0u) {
+            const uint32_t c0 = __hip_atomic_load(&Q->count[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            uint32_t best = 0u, bq = 1u;
+            for (uint32_t q = 1; q < HJR_WF_QUEUES; q++) {
+                const uint32_t cq = __hip_atomic_load(&Q->count[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (cq > best) { best = cq; bq = q; }
+            }
+            if (best >= 64u) pick = bq;
+            else if (c0 >= (uint32_t)HJR_WF_TRACE_MIN) pick = 0u;
+            else if (best > 0u && best >= c0) pick = bq;
+            else if (c0 > 0u) pick = 0u;
+            else if (__hip_atomic_load(&Q->live, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) pick = 6u;
+        }
+        pick = (uint32_t)__builtin_amdgcn_readfirstlane((int)pick);
+        if (pick == 6u) break;
+        if (pick == 7u) {
+            __builtin_amdgcn_s_sleep(16);
+#ifdef HJR_WF_WATCHDOG
+            if (WF_EXPIRED(3)) { // diagnostic build: a workgroup that waits this long has lost a context; record the queue state and leave
+                if (lane == 0u && atomicAdd(&P.stats[HJR_NSTAT], 1ull) == 0ull) {
+                    for (int q = 0; q < HJR_WF_QUEUES; q++) { P.stats[HJR_NSTAT + 1 + q] = Q->count[q]; P.stats[HJR_NSTAT + 6 + q] = Q->head[q]; P.stats[HJR_NSTAT + 11 + q] = Q->tail[q]; }
+                    P.stats[HJR_NSTAT + 16] = Q->live; P.stats[HJR_NSTAT + 17] = blockIdx.x; P.stats[HJR_NSTAT + 18] = Q->items_held;
+                }
+                break;
+            }
+#endif
+            continue;
+        }
+#ifdef HJR_WF_WATCHDOG
+        idle_spins = 0;
+#endif
+        if (pick == 0u) wf_trace_stage<STATS, WIDTH, BLOCK, ST>(P, Q, rings, nodes, tris, mats, ctx, stack, lc);
+        else wf_shade_stage<INTEGRATOR, STATS, AOVS, WIDTH, BLOCK, ST>(P, Q, rings, (int)pick, nodes, tris, mats, lights, ctx, wr, stack, lc);
+    }
+
+    if (STATS) {
+        lc[10] = stack.n_over;
+        for (int i = 0; i < HJR_NSTAT; i++) {
+            unsigned long long v = lc[i];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+            if (lane == 0 && v) atomicAdd(&P.stats[i], v);
+        }
+    }
+}

@@ -149,6 +149,33 @@ extern "C" int hjr_load_hdr_rgba32f(const char* path, float** rgba, int* w, int*
 
 extern "C" void hjr_free(void* p) { free(p); }
 
+// ---- pixel-tile shard: 8x8 tiles, tile t -> rank t % world; packed form = the rank's tiles back to back
+extern "C" uint32_t hjr_owned_tiles(uint32_t w, uint32_t h, uint32_t rank, uint32_t world)
+{
+    if (world == 0 || rank >= world) return 0;
+    const uint64_t n_tiles = (uint64_t)((w + 7u) / 8u) * ((h + 7u) / 8u);
+    return n_tiles > rank ? (uint32_t)((n_tiles - rank + world - 1) / world) : 0u;
+}
+template <bool PACK> static int tiles_copy(const float* src, float* dst, uint32_t w, uint32_t h, uint32_t rank, uint32_t world)
+{
+    if (!src || !dst || w == 0 || h == 0 || world == 0 || rank >= world) { set_error("hjr_pack_tiles / hjr_unpack_tiles: bad argument"); return HJR_ERR_ARG; }
+    const uint32_t tiles_x = (w + 7u) / 8u, n = hjr_owned_tiles(w, h, rank, world);
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t tile = i * world + rank, x0 = (tile % tiles_x) * 8u, y0 = (tile / tiles_x) * 8u;
+        for (uint32_t k = 0; k < 64u; k++) {
+            const uint32_t x = x0 + (k & 7u), y = y0 + (k >> 3);
+            float* p = PACK ? dst + ((size_t)i * 64 + k) * 4 : nullptr;
+            if (x < w && y < h) {
+                const size_t f = ((size_t)y * w + x) * 4, q = ((size_t)i * 64 + k) * 4;
+                if (PACK) memcpy(dst + q, src + f, 16); else memcpy(dst + f, src + q, 16);
+            } else if (PACK) p[0] = p[1] = p[2] = p[3] = 0.0f;
+        }
+    }
+    return HJR_OK;
+}
+extern "C" int hjr_pack_tiles(const float* frame, uint32_t w, uint32_t h, uint32_t rank, uint32_t world, float* packed) { return tiles_copy<true>(frame, packed, w, h, rank, world); }
+extern "C" int hjr_unpack_tiles(const float* packed, uint32_t w, uint32_t h, uint32_t rank, uint32_t world, float* frame) { return tiles_copy<false>(packed, frame, w, h, rank, world); }
+
 extern "C" int hjr_float4_to_srgb8(const float* rgba, uint8_t* out, uint32_t n)
 {
     if ((!rgba || !out) && n) { set_error("hjr_float4_to_srgb8: null argument"); return HJR_ERR_ARG; }

@@ -142,6 +142,9 @@ typedef struct hjr_params {
 } hjr_params;
 #define HJR_FLAG_STATS 1u        /* run the counting variant of the kernel (slower; fills hjr_stats) */
 #define HJR_FLAG_ZERO_UNOWNED 2u /* clear pixels of tiles this rank does not own (for a sum-reduce exchange) */
+#define HJR_FLAG_PACKED 4u       /* hjr_render_device only: the AOV buffers are PACKED — this rank's tiles only, back to back, each
+                                  * tile 64 float4 in row-major 8x8 order (hjr_owned_tiles(..) x 64 float4 per AOV).  What a
+                                  * multi-GPU frame exchanges: 1 / world_size of the frame per rank, no zero fill */
 
 typedef struct hjr_stats {
     uint64_t samples, closest_rays, shadow_rays, box_tests_closest, tri_tests_closest,
@@ -153,7 +156,7 @@ typedef struct hjr_stats {
     uint32_t lds_mode;
     uint32_t stack_need;         /* worst-case traversal stack entries per lane of the current BVH */
     uint32_t stack_lds_entries;  /* memory-path layouts: entries of a lane's stack kept in LDS; deeper ones overflow to HBM */
-    uint32_t _reserved;
+    uint32_t pipeline;           /* 0 = persistent megakernel (a lane owns a path), 1 = workgroup-local wavefront kernel (trace / shade batches) */
     uint64_t stack_overflow_pushes; /* HJR_FLAG_STATS launches: stack pushes that went to the HBM overflow (memory-path layouts) */
 } hjr_stats;
 
@@ -207,6 +210,15 @@ int hjr_render(hjr_ctx*, const hjr_params*, float* aov_color, float* aov_albedo,
 int hjr_render_device(hjr_ctx*, const hjr_params*, void* d_aov_color, void* d_aov_albedo, void* d_aov_normal,
                       void* hip_stream);
 int hjr_synchronize(hjr_ctx*);
+/* ---- pixel-tile shard helpers (no reference counterpart: the reference is single-GPU, renderer.h:1077-1078) ----
+ * Tiles are 8x8 pixels, numbered row-major, tile t belongs to rank t % world_size; rank r's i-th tile is i * world_size + r. */
+uint32_t hjr_owned_tiles(uint32_t width, uint32_t height, uint32_t rank, uint32_t world_size);
+/* host arrays: row-major float4 frame <-> packed [owned tile][64] float4 of one rank (frame pixels of other ranks untouched) */
+int hjr_pack_tiles(const float* frame_rgba, uint32_t width, uint32_t height, uint32_t rank, uint32_t world_size, float* packed_rgba);
+int hjr_unpack_tiles(const float* packed_rgba, uint32_t width, uint32_t height, uint32_t rank, uint32_t world_size, float* frame_rgba);
+/* the same on device pointers, asynchronous on `hip_stream` (NULL = the context's stream) */
+int hjr_pack_tiles_device(hjr_ctx*, const void* d_frame, uint32_t width, uint32_t height, uint32_t rank, uint32_t world_size, void* d_packed, void* hip_stream);
+int hjr_unpack_tiles_device(hjr_ctx*, const void* d_packed, uint32_t width, uint32_t height, uint32_t rank, uint32_t world_size, void* d_frame, void* hip_stream);
 /* OptixDenoiserManager::layerSet + denoise() — renderer/denoiser.h:42-189, renderer/renderer.h:1093-1120, 1258-1270:
  * (aov_color | guide albedo | guide normal) of in_w x in_h -> AOV_Output of out_w x out_h.  The OptiX AI network is closed, so
  * this is a REPLACEMENT with the same data flow, not a reproduction of its pixels: HJR_MODE_DEFAULT copies

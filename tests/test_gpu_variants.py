@@ -49,8 +49,11 @@ def oracle_frame(scene, key, w, h, spp, integrator):
     return _oracle_cache[k]
 
 
-def check_layout(scene, key, env, expect_mode, w=96, h=64, spp=4, integrators=ALL_INTEGRATORS, expect_overflow=False):
+def check_layout(scene, key, env, expect_mode, w=96, h=64, spp=4, integrators=ALL_INTEGRATORS, expect_overflow=False, pipeline=None):
     """Renders with the knobs set, asserts the layout, compares all AOVs (full variant) and the colour-only (lean) variant."""
+    env = dict(env)
+    if pipeline is not None:
+        env["HJR_PIPELINE"] = pipeline
     with knobs(**env):
         d = scene.device()  # host/frame.cpp reads the layout knobs here; the launch reads HJR_SHORT_STACK
         try:
@@ -59,6 +62,8 @@ def check_layout(scene, key, env, expect_mode, w=96, h=64, spp=4, integrators=AL
                 color, albedo, normal = d.render(scene.hjr_params(w, h, spp, integrator=integ))
                 st = d.stats()
                 assert st["lds_mode"] == expect_mode, (st["lds_mode"], expect_mode)
+                if pipeline is not None:
+                    assert st["pipeline"] == {"mega": 0, "wf": 1}[pipeline], st
                 assert_bitexact(color, oc, "aov_color (AOVS on, integrator %d)" % integ)
                 assert_bitexact(albedo, oa, "aov_albedo")
                 assert_bitexact(normal, on, "aov_normal")
@@ -123,3 +128,53 @@ def test_memory_layouts_on_a_deep_scene(tmp_path):
     check_layout(s, "ss8x88", {"HJR_BVH_WIDTH": 2}, expect_mode=3, w=64, h=36, spp=2, integrators=(hjr.INTEGRATOR_NEE, hjr.INTEGRATOR_MIS))
     check_layout(s, "ss8x88", {"HJR_SHORT_STACK": 3}, expect_mode=0, w=64, h=36, spp=2, integrators=(hjr.INTEGRATOR_NEE,),
                  expect_overflow=True)
+
+
+# ---- the workgroup-local wavefront kernel family (hjr_wavefront.hip.h): same layouts, same bar
+WF = "wf"
+
+
+def test_wavefront_default_layout(cornell):
+    check_layout(cornell, "cornell", {}, expect_mode=1, pipeline=WF)
+
+
+def test_wavefront_sizes_and_chunks(cornell):
+    """Ragged frames (items outside the frame edge are skipped and retried), one-pixel frames, several sample chunks per pixel,
+    small context pools (more turnover per context), and a pool larger than the frame."""
+    for (w, h, spp) in [(1, 1, 1), (7, 5, 3), (40, 24, 40), (200, 120, 35)]:
+        check_layout(cornell, "cornell", {}, expect_mode=1, w=w, h=h, spp=spp, integrators=(hjr.INTEGRATOR_NEE,), pipeline=WF)
+    check_layout(cornell, "cornell", {"HJR_WF_CAP": 256}, expect_mode=1, w=64, h=48, spp=9, pipeline=WF)
+    check_layout(cornell, "cornell", {"HJR_WF_CAP": 64}, expect_mode=1, w=33, h=17, spp=5, integrators=(hjr.INTEGRATOR_NEE, hjr.INTEGRATOR_MIS), pipeline=WF)
+
+
+def test_wavefront_lds16(cornell):
+    check_layout(cornell, "cornell", {"HJR_LDS_STACK16": 1}, expect_mode=2, pipeline=WF)
+
+
+@pytest.mark.parametrize("width,mode", [(4, 0), (2, 3)])
+def test_wavefront_memory_layouts_and_overflow(cornell, width, mode):
+    check_layout(cornell, "cornell", {"HJR_LDS_BVH": 0, "HJR_BVH_WIDTH": width}, expect_mode=mode, pipeline=WF)
+    check_layout(cornell, "cornell", {"HJR_LDS_BVH": 0, "HJR_BVH_WIDTH": width, "HJR_SHORT_STACK": 2}, expect_mode=mode,
+                 integrators=(hjr.INTEGRATOR_NEE, hjr.INTEGRATOR_MIS), expect_overflow=True, pipeline=WF)
+
+
+def test_wavefront_deep_scene(tmp_path):
+    s = StressScene(tmp_path, spheres=8, segments=88)
+    st = check_layout(s, "ss8x88", {}, expect_mode=0, w=64, h=36, spp=2, integrators=(hjr.INTEGRATOR_NEE, hjr.INTEGRATOR_PT), pipeline=WF)
+    assert st["stack_need"] > 16 and st["stack_lds_entries"] == 16
+
+
+def test_wavefront_statistics_match_the_megakernel(cornell):
+    """Ray / hit / sample counters are properties of the sample streams: both kernel families must report the same numbers."""
+    res = {}
+    for pipe in ("mega", WF):
+        with knobs(HJR_PIPELINE=pipe):
+            d = cornell.device()
+            try:
+                d.render(cornell.hjr_params(64, 64, 4, flags=hjr.FLAG_STATS), want_aovs=False)
+                res[pipe] = d.stats()
+            finally:
+                d.close()
+    for k in ("samples", "closest_rays", "shadow_rays", "shaded_hits", "light_samples", "nan_samples", "box_tests_closest",
+              "tri_tests_closest", "box_tests_shadow", "tri_tests_shadow"):
+        assert res["mega"][k] == res[WF][k], (k, res["mega"][k], res[WF][k])

@@ -67,7 +67,8 @@ class RenderOption(C.Structure):
                 ("camera_animation_id", C.c_int32), ("render_mode", C.c_int32), ("ptxfile_path", C.c_char * 512),
                 ("use_IBL", C.c_int32), ("IBL_path", C.c_char * 512), ("IBL_intensity", C.c_float),
                 ("scene_sky_default", C.c_float * 3), ("use_date", C.c_int32), ("save_renderOption", C.c_int32),
-                ("LUT_path", C.c_char * 512), ("seed", C.c_uint32), ("integrator", C.c_int32)]
+                ("LUT_path", C.c_char * 512), ("seed", C.c_uint32), ("integrator", C.c_int32),
+                ("devices", C.c_uint32), ("tile", C.c_uint32)]
 
 
 class Camera(C.Structure):

@@ -1,18 +1,170 @@
-// henjou_cli <render_option.json> [device] — stands in for the reference's missing main()
-// (HenjouRenderer/henjouRenderer.cpp: Renderer r; r.initializeAndRender(path)).
+// henjou_cli <render_option.json> [device] [--devices N]
+// Stands in for the reference's missing main() (HenjouRenderer/henjouRenderer.cpp: Renderer r; r.initializeAndRender(path)).
+//
+// One GPU: hjr_render_file.  N GPUs of one node ("Henjou_HIP": {"devices": N} in the JSON, or --devices N): this process forks N
+// rank processes BEFORE anything touches a GPU (fork + exec of itself with --rank), one per GPU; each loads the scene, renders its
+// 8x8 pixel tiles of every frame (tile t -> rank t % N, HJR_FLAG_PACKED: only owned tiles are produced, [owned tile][64] float4)
+// and the ranks meet in ONE RCCL collective per frame: ncclGather of the packed tiles onto rank 0 over xGMI (point-to-point sends,
+// all peers in parallel, 1 / N of the frame per rank; SURVEY.md §8e option b).  Rank 0 scatters the N blocks into the frame
+// (hjr_unpack_tiles_device), downloads it and writes <image_name>_<fff>.png exactly like the single-GPU path.  The assembled
+// frame is bit-identical to the 1-GPU frame: per-pixel sample order does not depend on which GPU owns the pixel.
+// The reference has no counterpart (one process, one stream: renderer/renderer.h:1077-1078).
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <sys/wait.h>
+#include <unistd.h>
+
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
 
 #include "../../include/henjou_hip.h"
 
+#define HIPX(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { fprintf(stderr, "henjou_cli[%d]: %s: %s\n", rank, #call, hipGetErrorString(e_)); return 1; } } while (0)
+#define NCCLX(call) do { ncclResult_t e_ = (call); if (e_ != ncclSuccess) { fprintf(stderr, "henjou_cli[%d]: %s: %s\n", rank, #call, ncclGetErrorString(e_)); return 1; } } while (0)
+#define HJRX(call) do { int e_ = (call); if (e_ != HJR_OK) { fprintf(stderr, "henjou_cli[%d]: %s -> %d: %s\n", rank, #call, e_, hjr_last_error()); return 1; } } while (0)
+
+// one rank of a multi-GPU render (its own process; GPU `rank` of the node)
+static int run_rank(const char* json, int rank, int world, const char* id_path)
+{
+    hjr_render_option opt;
+    HJRX(hjr_load_render_option(json, &opt));
+    if (opt.render_mode != HJR_MODE_DEFAULT) { fprintf(stderr, "henjou_cli: the multi-GPU path renders Render_mode \"Default\" only\n"); return 1; }
+    hjr_scene* scene = nullptr;
+    HJRX(hjr_scene_load_gltf(opt.gltf_path, opt.gltf_name, &opt, &scene));
+    hjr_scene_view view;
+    HJRX(hjr_scene_get_view(scene, &view));
+    hjr_ctx* ctx = nullptr;
+    HJRX(hjr_create(rank, &ctx));
+    HJRX(hjr_upload_scene(ctx, &view));
+    {
+        uint8_t* lut = nullptr; int lw = 0, lh = 0;
+        if (hjr_load_png_rgba8(opt.LUT_path, &lut, &lw, &lh) == HJR_OK) { HJRX(hjr_set_lut(ctx, lut, lw, lh)); hjr_free(lut); }
+        if (opt.use_IBL) {
+            float* sky = nullptr; int sw = 0, sh = 0;
+            if (hjr_load_hdr_rgba32f(opt.IBL_path, &sky, &sw, &sh) == HJR_OK) { HJRX(hjr_set_sky(ctx, sky, sw, sh)); hjr_free(sky); }
+        }
+    }
+    // RCCL communicator: rank 0 creates the id and hands it over through a file the parent named
+    HIPX(hipSetDevice(rank));
+    ncclUniqueId id;
+    if (rank == 0) {
+        NCCLX(ncclGetUniqueId(&id));
+        std::string tmp = std::string(id_path) + ".tmp";
+        FILE* f = fopen(tmp.c_str(), "wb");
+        if (!f || fwrite(&id, sizeof(id), 1, f) != 1) { fprintf(stderr, "henjou_cli: cannot write %s\n", tmp.c_str()); return 1; }
+        fclose(f);
+        rename(tmp.c_str(), id_path);
+    } else {
+        FILE* f = nullptr;
+        for (int tries = 0; tries < 6000 && !(f = fopen(id_path, "rb")); tries++) std::this_thread::sleep_for(std::chrono::milliseconds(10));
+        if (!f || fread(&id, sizeof(id), 1, f) != 1) { fprintf(stderr, "henjou_cli[%d]: no RCCL id from rank 0\n", rank); return 1; }
+        fclose(f);
+    }
+    ncclComm_t comm;
+    NCCLX(ncclCommInitRank(&comm, world, id, rank));
+    hipStream_t st;
+    HIPX(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+
+    const uint32_t W = opt.image_width, H = opt.image_height;
+    const size_t block = (size_t)hjr_owned_tiles(W, H, 0, (uint32_t)world) * 64; // float4 per rank (rank 0 owns the most tiles; others pad)
+    float *d_packed = nullptr, *d_all = nullptr, *d_frame = nullptr;
+    HIPX(hipMalloc(&d_packed, block * 16));
+    HIPX(hipMemset(d_packed, 0, block * 16));
+    std::vector<float> frame;
+    if (rank == 0) {
+        HIPX(hipMalloc(&d_all, block * 16 * world));
+        HIPX(hipMalloc(&d_frame, (size_t)W * H * 16));
+        frame.resize((size_t)W * H * 4);
+    }
+    std::vector<float> m((size_t)view.n_instances * 12), inv((size_t)view.n_instances * 12);
+    for (uint32_t f = opt.start_frame; f < opt.end_frame; f++) {
+        const float time = f / float(opt.fps); // renderer.h:1128
+        HJRX(hjr_scene_eval_transforms(scene, time, m.data(), inv.data()));
+        HJRX(hjr_set_transforms(ctx, m.data(), inv.data(), view.n_instances));
+        hjr_params p;
+        memset(&p, 0, sizeof(p));
+        p.width = W; p.height = H; p.spp = opt.max_spp; p.frame = f; p.seed = opt.seed; p.integrator = (uint32_t)opt.integrator;
+        HJRX(hjr_scene_eval_camera(scene, &opt, time, &p.camera));
+        for (int k = 0; k < 3; k++) p.sky[k] = opt.scene_sky_default[k];
+        p.ibl_intensity = opt.IBL_intensity;
+        p.rank = (uint32_t)rank; p.world_size = (uint32_t)world; p.flags = HJR_FLAG_PACKED;
+        const auto t0 = std::chrono::steady_clock::now();
+        HJRX(hjr_render_device(ctx, &p, d_packed, nullptr, nullptr, st));
+        NCCLX(ncclGather(d_packed, d_all, block * 4, ncclFloat, 0, comm, st)); // the one data-path collective of a frame
+        if (rank == 0) {
+            for (int r = 0; r < world; r++) HJRX(hjr_unpack_tiles_device(ctx, d_all + (size_t)r * block * 4, W, H, (uint32_t)r, (uint32_t)world, d_frame, st));
+            HIPX(hipMemcpyAsync(frame.data(), d_frame, frame.size() * 4, hipMemcpyDeviceToHost, st));
+        }
+        HIPX(hipStreamSynchronize(st));
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        hjr_stats s;
+        if (hjr_get_stats(ctx, &s) == HJR_OK)
+            fprintf(stderr, "[henjou %d/%d] frame %u: kernel %.3f ms, render + gather + assemble %.3f ms\n", rank, world, f, s.last_kernel_ms, ms);
+        if (rank == 0) {
+            std::vector<uint8_t> rgba8((size_t)W * H * 4);
+            HJRX(hjr_float4_to_srgb8(frame.data(), rgba8.data(), W * H));
+            std::string n = std::to_string(f); // renderer.h:1291-1302
+            while (n.size() < 3) n = "0" + n;
+            HJRX(hjr_write_png((std::string(opt.image_name) + "_" + n + ".png").c_str(), rgba8.data(), W, H, 1));
+        }
+    }
+    ncclCommDestroy(comm);
+    hjr_destroy(ctx);
+    hjr_scene_free(scene);
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
-    const char* path = argc > 1 ? argv[1] : "render_option.json";
-    int device = argc > 2 ? atoi(argv[2]) : 0;
-    int rc = hjr_render_file(path, device);
-    if (rc != HJR_OK) {
-        fprintf(stderr, "henjou_cli: error %d: %s\n", rc, hjr_last_error());
-        return 1;
+    const char* path = "render_option.json";
+    int device = 0, devices = 0, rank = -1, world = 0;
+    const char* id_path = nullptr;
+    int positional = 0;
+    for (int i = 1; i < argc; i++) {
+        const std::string a = argv[i];
+        if (a == "--devices" && i + 1 < argc) devices = atoi(argv[++i]);
+        else if (a == "--rank" && i + 1 < argc) rank = atoi(argv[++i]);
+        else if (a == "--world" && i + 1 < argc) world = atoi(argv[++i]);
+        else if (a == "--id" && i + 1 < argc) id_path = argv[++i];
+        else if (positional == 0) { path = argv[i]; positional++; }
+        else if (positional == 1) { device = atoi(argv[i]); positional++; }
     }
-    return 0;
+    if (rank >= 0) return (world > 1 && id_path) ? run_rank(path, rank, world, id_path) : 2; // a rank process of a multi-GPU render
+    if (devices == 0) { // the JSON decides (host-only parse: no GPU is touched here)
+        hjr_render_option opt;
+        if (hjr_load_render_option(path, &opt) != HJR_OK) { fprintf(stderr, "henjou_cli: error: %s\n", hjr_last_error()); return 1; }
+        devices = (int)opt.devices;
+    }
+    if (devices <= 1) {
+        int rc = hjr_render_file(path, device);
+        if (rc != HJR_OK) { fprintf(stderr, "henjou_cli: error %d: %s\n", rc, hjr_last_error()); return 1; }
+        return 0;
+    }
+    // launcher: one rank process per GPU, started before any GPU call in this process
+    char id_file[] = "/tmp/hjr_rccl_id_XXXXXX";
+    const int fd = mkstemp(id_file);
+    if (fd < 0) { perror("henjou_cli: mkstemp"); return 1; }
+    close(fd);
+    unlink(id_file); // rank 0 creates it; the others wait for it to appear
+    std::vector<pid_t> kids;
+    for (int r = 0; r < devices; r++) {
+        const pid_t pid = fork();
+        if (pid < 0) { perror("henjou_cli: fork"); return 1; }
+        if (pid == 0) {
+            const std::string rs = std::to_string(r), ws = std::to_string(devices);
+            execl("/proc/self/exe", argv[0], path, "--rank", rs.c_str(), "--world", ws.c_str(), "--id", id_file, (char*)nullptr);
+            perror("henjou_cli: exec");
+            _exit(127);
+        }
+        kids.push_back(pid);
+    }
+    int rc = 0;
+    for (pid_t k : kids) { int stt = 0; waitpid(k, &stt, 0); if (!WIFEXITED(stt) || WEXITSTATUS(stt) != 0) rc = 1; }
+    unlink(id_file);
+    return rc;
 }

@@ -290,8 +290,10 @@ template <int I, bool S, bool LDS, bool S16, int W, bool A> static int launch_wf
     if (blocks > max_useful) blocks = max_useful ? max_useful : 1;
     KParams k2 = kp;
     k2.wf_cap = cap;
-    k2.wf_plane_stride = (uint32_t)(blocks * cap);
-    const size_t ctx_bytes = (size_t)(A ? HJR_WF_PLANES_FULL : HJR_WF_PLANES_LEAN) * 16 * k2.wf_plane_stride;
+    k2.wf_refill = HJR_WF_REFILL; k2.wf_trace_min = HJR_WF_TRACE_MIN;
+    if (const char* e = getenv("HJR_WF_REFILL")) { int v = atoi(e); if (v >= 1 && v <= 64) k2.wf_refill = (uint32_t)v; }       // tuning knobs
+    if (const char* e = getenv("HJR_WF_TRACE_MIN")) { int v = atoi(e); if (v >= 1 && v <= 4096) k2.wf_trace_min = (uint32_t)v; }
+    const size_t ctx_bytes = (size_t)(A ? HJR_WF_CTX_F4_FULL : HJR_WF_CTX_F4_LEAN) * 16 * blocks * cap;
     if (c->d_wf_ctx.cap < ctx_bytes) {
         c->d_wf_ctx.release();
         if (hipMalloc(&c->d_wf_ctx.p, ctx_bytes) != hipSuccess) return -1;
@@ -559,17 +561,17 @@ static int fetch_stats(hjr_ctx* c, hipStream_t st)
     for (int i = 0; i < 10; i++) dst[i] = h[i];
     c->stats.stack_overflow_pushes = h[10];
 #ifdef HJR_WF_WATCHDOG
-    { // diagnostic build only: did a workgroup of the wavefront kernel give up waiting?
+    { // diagnostic build only: did the wavefront kernel run into its deadline, and where?
         unsigned long long wd[19];
         HIPCHK(hipMemcpy(wd, (char*)c->d_work.p + 16 + HJR_NSTAT * 8, sizeof(wd), hipMemcpyDeviceToHost));
-        unsigned int word = 0;
-        (void)hipMemcpyFromSymbol(&word, HIP_SYMBOL(wf_watchdog_word), 4);
         unsigned int where[8] = { 0 };
         (void)hipMemcpyFromSymbol(where, HIP_SYMBOL(wf_where), sizeof(where));
-        if (where[1] | where[2] | where[3] | where[4] | where[5]) fprintf(stderr, "[hjr wf watchdog] deadline hit in: take %u, push-wait %u, scheduler %u, trace loop %u, pop %u\n", where[1], where[2], where[3], where[4], where[5]);
-        if (wd[0] || word) {
-            fprintf(stderr, "[hjr wf watchdog] %llu workgroup-waves gave up (take-spin word %08x); first: block %llu live %llu items_held %llu\n", wd[0], word, wd[17], wd[16], wd[18]);
-            for (int q = 0; q < 5; q++) fprintf(stderr, "   queue %d: count %llu head %llu tail %llu\n", q, wd[1 + q], wd[6 + q], wd[11 + q]);
+        if (where[1] | where[2] | where[3] | where[4] | where[5] | where[6]) {
+            fprintf(stderr, "[hjr wf watchdog] deadline hit in (lane counts): take %u, push slot-wait %u, push publish-wait %u, trace loop %u, pop %u, scheduler %u\n", where[1], where[2], where[3], where[4], where[5], where[6]);
+            fprintf(stderr, "[hjr wf watchdog] first workgroup to give up: block %llu live %llu items_held %llu\n", wd[17], wd[16], wd[18]);
+            for (int q = 0; q < 5; q++) fprintf(stderr, "   queue %d: commit %llu head %llu tail %llu\n", q, wd[1 + q], wd[6 + q], wd[11 + q]);
+            unsigned int zero[8] = { 0 };
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(wf_where), zero, sizeof(zero));
         }
     }
 #endif

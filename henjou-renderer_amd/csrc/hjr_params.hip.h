@@ -46,9 +46,9 @@ struct KParams {
     uint32_t cost_div;               // 64 * spp: rays per tile at one ray per sample
     uint32_t spill_stride;           // lanes in the grid
     uint32_t stack_lds_entries;      // memory-path kernels: stack entries per lane kept in LDS (the rest overflow to stack_spill)
-    float4* wf_ctx;                  // wavefront kernel: context planes, [plane][workgroup][wf_cap] float4 (hjr_wavefront.hip.h)
+    float4* wf_ctx;                  // wavefront kernel: context records, [workgroup][wf_cap] x 128 (192) bytes (hjr_wavefront.hip.h)
     uint32_t wf_cap;                 // contexts per workgroup (power of two, <= 32768: ids travel as uint16 + 1)
-    uint32_t wf_plane_stride;        // contexts of all workgroups = grid x wf_cap
+    uint32_t wf_refill, wf_trace_min; // trace-stage turnover threshold (lanes waiting) / scheduler preference for TRACE (queued rays)
     float4* part_color;              // [n_chunks][owned tile][64] chunk sums when n_chunks > 1
     float4* part_albedo;
     float4* part_normal;

@@ -28,16 +28,14 @@
 #define HJR_WF_TRACE_MIN 32 /* scheduler: a TRACE batch is preferred over a partial SHADE batch from this many queued rays on */
 #endif
 #define HJR_WF_QUEUES 5
-#define HJR_WF_PLANES_LEAN 8
-#define HJR_WF_PLANES_FULL 10
 
 // queue header in LDS (after the scene tables); rings of uint16 ids follow it
 struct WfShared {
-    uint32_t head[HJR_WF_QUEUES];  // next ring position to take
-    uint32_t tail[HJR_WF_QUEUES];  // next ring position to reserve
-    uint32_t count[HJR_WF_QUEUES]; // committed entries not yet claimed
-    uint32_t live;                 // contexts not yet retired
-    uint32_t items_held;           // work items sitting unassigned in the private ranges of this workgroup's waves (WaveRange::held)
+    uint32_t head[HJR_WF_QUEUES];   // next ring position to take
+    uint32_t tail[HJR_WF_QUEUES];   // next ring position to reserve
+    uint32_t commit[HJR_WF_QUEUES]; // positions below this are written and may be taken (published in reservation order)
+    uint32_t live;                  // contexts not yet retired
+    uint32_t items_held;            // work items sitting unassigned in the private ranges of this workgroup's waves (WaveRange::held)
 };
 
 // context flags word (plane 1 .w)
@@ -52,9 +50,8 @@ struct WfShared {
 #define WF_MISS 0x7fffffffu
 
 #ifdef HJR_WF_WATCHDOG
-// diagnostic build: every loop of the kernel gives up 1.5 s after the workgroup started (100 MHz real-time counter) and records where
-__device__ unsigned int wf_watchdog_word;
-__device__ unsigned int wf_where[8]; // [1] take, [2] push wait, [3] scheduler wait, [4] trace loop, [5] pop CAS
+// diagnostic build: every waiting loop of the kernel gives up 1.5 s after the workgroup started (100 MHz real-time counter) and records where
+__device__ unsigned int wf_where[8]; // [1] take, [2] push: slot wait, [3] push: publish wait, [4] trace loop, [5] pop, [6] scheduler
 __shared__ unsigned long long wf_t0;
 HD bool wf_expired(int where)
 {
@@ -68,18 +65,25 @@ HD bool wf_expired(int where)
 #endif
 
 // ---- queue operations.  Every one is called by all 64 lanes of a wave at a wave-uniform point.
-// Claims up to `want` committed entries of queue q: returns how many (wave-uniform) and the first ring position.
+// Protocol: a producer reserves ring positions (tail), writes them, and PUBLISHES them in reservation order (commit); a taker
+// claims published positions (head), so what it claims is always written and a taker never waits.  A slot holds id + 1 and is
+// zeroed by its taker; a producer whose reserved slot still holds the entry of one lap ago (claimed, about to be read) waits for
+// that zero.  Waiting is therefore one-directional — producers wait for takers and for earlier producers, takers for nobody —
+// and cannot deadlock.  (An earlier form let takers claim committed COUNTS and wait for the slot: two producers one lap apart could
+// then write the same slot, and the taker's wave-wide wait loop delayed its clears: lost entries and deadlocks under load.)
+// Claims up to `want` published entries of queue q: returns how many (wave-uniform) and the first ring position.
 HD uint32_t wf_pop(WfShared* Q, int q, uint32_t want, uint32_t& start)
 {
     uint32_t got = 0, st = 0;
     if ((threadIdx.x & 63u) == 0u && want) {
-        uint32_t c = __hip_atomic_load(&Q->count[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        while (c != 0u) {
-            if (WF_EXPIRED(5)) break;
-            const uint32_t take = c < want ? c : want;
-            const uint32_t old = atomicCAS(&Q->count[q], c, c - take);
-            if (old == c) { got = take; st = atomicAdd(&Q->head[q], take); break; }
-            c = old;
+        uint32_t h = __hip_atomic_load(&Q->head[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        for (;;) {
+            const uint32_t avail = __hip_atomic_load(&Q->commit[q], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) - h;
+            if (avail == 0u || avail > 0x7fffffffu || WF_EXPIRED(5)) break; // (a head read before a concurrent claim can be ahead of this commit)
+            const uint32_t take = avail < want ? avail : want;
+            const uint32_t old = atomicCAS(&Q->head[q], h, h + take);
+            if (old == h) { got = take; st = h; break; }
+            h = old;
         }
     }
     start = (uint32_t)__builtin_amdgcn_readfirstlane((int)st);
@@ -87,33 +91,18 @@ HD uint32_t wf_pop(WfShared* Q, int q, uint32_t want, uint32_t& start)
     if (got) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     return got;
 }
-// The id at ring position pos of queue q.  A claimed position may belong to a producer that has reserved it but not written it
-// yet (commits of different producers can overtake each other): wait for the non-zero marker, then free the slot.
+// The id at a claimed ring position (always written: see the protocol above); frees the slot.
 HD uint32_t wf_take(uint16_t* rings, int q, uint32_t pos, uint32_t cap)
 {
     volatile uint16_t* slot = rings + (size_t)q * cap + (pos & (cap - 1u));
-    // Each lane frees its slot in the loop iteration after the one that read it, i.e. while other lanes of the wave may still be
-    // waiting for theirs: a clear that waited for the whole wave could land after the slot's next producer has reused it (lost
-    // entry), or keep that producer waiting for a wave that is itself waiting for a producer (deadlock).
-    uint32_t v = 0u;
-    bool cleared = false;
-#ifdef HJR_WF_WATCHDOG
-    uint32_t spins = 0;
-#endif
-    while (!cleared) {
-        if (v == 0u) {
-            v = *slot;
-#ifdef HJR_WF_WATCHDOG
-            if (v == 0u && (++spins & 1023u) == 0u && WF_EXPIRED(1)) { wf_watchdog_word = 0x80000000u | ((uint32_t)q << 24) | (pos & 0xffffffu); v = 1u; }
-#endif
-        } else { *slot = 0; cleared = true; }
-    }
+    const uint32_t v = *slot;
+    *slot = 0;
     return v - 1u;
 }
 // Appends the ids of the lanes with `flag` to queue q.  Everything the wave wrote before (context planes in memory, ring slots in
-// LDS) is made visible to the workgroup before the entries are committed.
+// LDS) is visible to the workgroup before the entries are published.
 HD void wf_push(WfShared* Q, uint16_t* rings, int q, bool flag, uint32_t id, uint32_t cap)
-{
+{ // (the release fence below also orders this wave's earlier context stores: one wait covers every push of a hand-over)
     const unsigned long long m = __ballot(flag);
     if (m == 0ull) return;
     const uint32_t n = (uint32_t)__popcll(m);
@@ -122,41 +111,46 @@ HD void wf_push(WfShared* Q, uint16_t* rings, int q, bool flag, uint32_t id, uin
     if ((threadIdx.x & 63u) == 0u) pos = atomicAdd(&Q->tail[q], n);
     pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos);
     if (flag) {
-        // a ring holds at most wf_cap ids, so the reserved slot is free unless its previous taker has claimed it but not read it yet
-        // (possible only when the whole pool passes through one queue meanwhile): wait for the taker's clear before reusing it
         volatile uint16_t* slot = rings + (size_t)q * cap + ((pos + prefix) & (cap - 1u));
-        while (*slot != 0) { if (WF_EXPIRED(2)) break; }
+        while (*slot != 0) { if (WF_EXPIRED(2)) break; } // the entry of one lap ago is claimed (a ring holds at most wf_cap ids): its taker zeroes it at once
         *slot = (uint16_t)(id + 1u);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if ((threadIdx.x & 63u) == 0u) atomicAdd(&Q->count[q], n);
+    if ((threadIdx.x & 63u) == 0u) {
+        while (__hip_atomic_load(&Q->commit[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != pos) { if (WF_EXPIRED(3)) break; } // earlier reservations publish first
+        __hip_atomic_store(&Q->commit[q], pos + n, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
 }
 
-// ---- context planes: float4 arrays of `stride` contexts each (all workgroups), this workgroup's contexts at [0, cap) of `ctx`
+// ---- context records: one per context id, HJR_WF_CTX_F4_LEAN float4 = 128 bytes = exactly one cache line (the albedo / normal
+// variant appends two float4 and pads to 192 bytes).  A stage loads / stores a context with consecutive dwordx4 accesses of ONE
+// line per lane; plane-major arrays (one line per 16-byte access) cost 8x the L2 traffic and ran 1.7x slower.
 //   0: ro.xyz rd.x   1: rd.yz sh_tmax flags   2: sh_d.xyz item   3: thr.xyz s   4: L.xyz it_cost   5: sumL.xyz (depth | rng_depth << 8)
 //   6: sh_contrib.xyz -   7: hit t b1 b2 (k | occluded << 31)   8: sumA.xyz -   9: sumN.xyz -      (8, 9: AOVS variant only)
-template <bool AOVS> HD void wf_store_ctx(float4* ctx, size_t stride, uint32_t id, const LaneCtx& c, bool tracing)
+#define HJR_WF_CTX_F4_LEAN 8
+#define HJR_WF_CTX_F4_FULL 12
+template <bool AOVS> HD void wf_store_ctx(float4* ctx, uint32_t id, const LaneCtx& c, bool tracing)
 {
     const uint32_t flags = (c.has_item ? WF_HAS_ITEM : 0u) | (c.dead ? WF_DEAD : 0u) | (c.path_live ? WF_PATH_LIVE : 0u) | (c.fin_pending ? WF_FIN_PENDING : 0u) |
                            (c.write_pending ? WF_WRITE_PENDING : 0u) | (c.sh_valid ? WF_SH_VALID : 0u) | (c.fresh ? WF_FRESH : 0u) | (tracing ? WF_TRACING : 0u);
-    float4* p = ctx + id;
-    p[0 * stride] = make_float4(c.ps.ro.x, c.ps.ro.y, c.ps.ro.z, c.ps.rd.x);
-    p[1 * stride] = make_float4(c.ps.rd.y, c.ps.rd.z, c.sh_tmax, bits2f(flags));
-    p[2 * stride] = make_float4(c.sh_d.x, c.sh_d.y, c.sh_d.z, bits2f(c.item));
-    p[3 * stride] = make_float4(c.ps.thr.x, c.ps.thr.y, c.ps.thr.z, bits2f(c.s));
-    p[4 * stride] = make_float4(c.ps.L.x, c.ps.L.y, c.ps.L.z, bits2f(c.it_cost));
-    p[5 * stride] = make_float4(c.sumL.x, c.sumL.y, c.sumL.z, bits2f((uint32_t)c.ps.depth | (c.ps.rng_depth << 8)));
-    p[6 * stride] = make_float4(c.sh_contrib.x, c.sh_contrib.y, c.sh_contrib.z, 0.0f);
+    float4* p = ctx + (size_t)id * (AOVS ? HJR_WF_CTX_F4_FULL : HJR_WF_CTX_F4_LEAN);
+    p[0] = make_float4(c.ps.ro.x, c.ps.ro.y, c.ps.ro.z, c.ps.rd.x);
+    p[1] = make_float4(c.ps.rd.y, c.ps.rd.z, c.sh_tmax, bits2f(flags));
+    p[2] = make_float4(c.sh_d.x, c.sh_d.y, c.sh_d.z, bits2f(c.item));
+    p[3] = make_float4(c.ps.thr.x, c.ps.thr.y, c.ps.thr.z, bits2f(c.s));
+    p[4] = make_float4(c.ps.L.x, c.ps.L.y, c.ps.L.z, bits2f(c.it_cost));
+    p[5] = make_float4(c.sumL.x, c.sumL.y, c.sumL.z, bits2f((uint32_t)c.ps.depth | (c.ps.rng_depth << 8)));
+    p[6] = make_float4(c.sh_contrib.x, c.sh_contrib.y, c.sh_contrib.z, 0.0f);
     if (AOVS) {
-        p[8 * stride] = make_float4(c.sumA.x, c.sumA.y, c.sumA.z, 0.0f);
-        p[9 * stride] = make_float4(c.sumN.x, c.sumN.y, c.sumN.z, 0.0f);
+        p[8] = make_float4(c.sumA.x, c.sumA.y, c.sumA.z, 0.0f);
+        p[9] = make_float4(c.sumN.x, c.sumN.y, c.sumN.z, 0.0f);
     }
 }
-template <bool AOVS> HD void wf_load_ctx(const float4* ctx, size_t stride, uint32_t id, LaneCtx& c, bool& tracing, float4& hitrec)
+template <bool AOVS> HD void wf_load_ctx(const float4* ctx, uint32_t id, LaneCtx& c, bool& tracing, float4& hitrec)
 {
-    const float4* p = ctx + id;
-    const float4 a = p[0 * stride], b = p[1 * stride], d = p[2 * stride], e = p[3 * stride], f = p[4 * stride], g = p[5 * stride], h = p[6 * stride];
-    hitrec = p[7 * stride];
+    const float4* p = ctx + (size_t)id * (AOVS ? HJR_WF_CTX_F4_FULL : HJR_WF_CTX_F4_LEAN);
+    const float4 a = p[0], b = p[1], d = p[2], e = p[3], f = p[4], g = p[5], h = p[6];
+    hitrec = p[7];
     const uint32_t flags = f2bits(b.w);
     c.has_item = flags & WF_HAS_ITEM; c.dead = flags & WF_DEAD; c.path_live = flags & WF_PATH_LIVE; c.fin_pending = flags & WF_FIN_PENDING;
     c.write_pending = flags & WF_WRITE_PENDING; c.sh_valid = flags & WF_SH_VALID; c.fresh = flags & WF_FRESH;
@@ -168,7 +162,7 @@ template <bool AOVS> HD void wf_load_ctx(const float4* ctx, size_t stride, uint3
     c.sumL = V(g.x, g.y, g.z); c.ps.depth = (int)(f2bits(g.w) & 0xffu); c.ps.rng_depth = f2bits(g.w) >> 8;
     c.sh_contrib = V(h.x, h.y, h.z);
     if (AOVS) {
-        const float4 sa = p[8 * stride], sn = p[9 * stride];
+        const float4 sa = p[8], sn = p[9];
         c.sumA = V(sa.x, sa.y, sa.z); c.sumN = V(sn.x, sn.y, sn.z);
     } else { c.sumA = V1(0.0f); c.sumN = V1(0.0f); }
 }
@@ -176,11 +170,10 @@ template <bool AOVS> HD void wf_load_ctx(const float4* ctx, size_t stride, uint3
 // ---- TRACE stage: the fused two-ray traversal of the megakernel (hjr_traverse.hip.h::traverse_fused: shadow ray, then the
 // closest-hit ray, "while-while") with lane-level turnover.  phase: 0 shadow ray, 1 closest-hit ray, 2 empty, 3 finished (result
 // not handed over yet).  Returns when no lane has a ray and the TRACE queue is empty.
-template <bool STATS, int WIDTH, int BLOCK, typename ST>
+template <bool STATS, int WIDTH, int BLOCK, int CTXF4, typename ST>
 HD void wf_trace_stage(const KParams& P, WfShared* Q, uint16_t* rings, const float4* nodes, const float4* tris, const float4* mats, float4* ctx, ST& stack, unsigned long long* lc)
 {
     const uint32_t cap = P.wf_cap;
-    const size_t stride = P.wf_plane_stride;
     const float tmin = 0.001f;
     const f3 cam_o = V(P.cam_pos[0], P.cam_pos[1], P.cam_pos[2]);
     int phase = 2, sp = 0;
@@ -193,7 +186,7 @@ HD void wf_trace_stage(const KParams& P, WfShared* Q, uint16_t* rings, const flo
     for (;;) {
         if (WF_EXPIRED(4)) return;
         const uint32_t n_wait = (uint32_t)__popcll(__ballot(phase >= 2));
-        if (n_wait >= (uint32_t)HJR_WF_REFILL || n_wait == 64u) {
+        if (n_wait >= P.wf_refill || n_wait == 64u) {
             // ---- hand the finished rays over: hit record -> context plane 7, context id -> the SHADE queue of what was hit
             const bool fin = phase == 3;
             if (__ballot(fin)) {
@@ -206,7 +199,7 @@ HD void wf_trace_stage(const KParams& P, WfShared* Q, uint16_t* rings, const flo
                         const float4 m0 = m[0], m3 = m[3];
                         cls = f2bits(m3.x) != 0 ? 0u : (f2bits(m3.y) != 0 ? 3u : (m0.w > 0.5f ? 2u : 1u)); // light | glass | metallic (msGGX) | Disney
                     }
-                    ctx[7 * stride + id] = make_float4(hit.t, hit.b1, hit.b2, bits2f(kk | (occluded ? 0x80000000u : 0u)));
+                    ctx[(size_t)id * CTXF4 + 7] = make_float4(hit.t, hit.b1, hit.b2, bits2f(kk | (occluded ? 0x80000000u : 0u)));
                 }
                 for (uint32_t q = 0; q < 4u; q++) wf_push(Q, rings, 1 + (int)q, fin && cls == q, id, cap);
                 if (fin) phase = 2;
@@ -219,7 +212,8 @@ HD void wf_trace_stage(const KParams& P, WfShared* Q, uint16_t* rings, const flo
                 const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(m_idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_idle, 0u));
                 if (phase == 2 && prefix < got) {
                     id = wf_take(rings, 0, start + prefix, cap);
-                    const float4 p0 = ctx[0 * stride + id], p1 = ctx[1 * stride + id], p2 = ctx[2 * stride + id];
+                    const float4* cp = ctx + (size_t)id * CTXF4;
+                    const float4 p0 = cp[0], p1 = cp[1], p2 = cp[2];
                     const uint32_t flags = f2bits(p1.w);
                     ro = V(p0.x, p0.y, p0.z); db = V(p0.w, p1.x, p1.y); a_tmax = p1.z;
                     b_valid = flags & WF_TRACING; fresh = flags & WF_FRESH;
@@ -283,7 +277,6 @@ HD void wf_shade_stage(const KParams& P, WfShared* Q, uint16_t* rings, int q, co
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t cap = P.wf_cap;
-    const size_t stride = P.wf_plane_stride;
     uint32_t start = 0;
     const uint32_t got = wf_pop(Q, q, 64u, start);
     if (got == 0u) return;
@@ -296,7 +289,7 @@ HD void wf_shade_stage(const KParams& P, WfShared* Q, uint16_t* rings, int q, co
     if (have) {
         id = wf_take(rings, q, start + lane, cap);
         float4 hr;
-        wf_load_ctx<AOVS>(ctx, stride, id, c, tracing, hr);
+        wf_load_ctx<AOVS>(ctx, id, c, tracing, hr);
         const uint32_t kk = f2bits(hr.w);
         Hit h;
         h.t = hr.x; h.b1 = hr.y; h.b2 = hr.z; h.k = kk & 0x7fffffffu;
@@ -308,7 +301,7 @@ HD void wf_shade_stage(const KParams& P, WfShared* Q, uint16_t* rings, int q, co
     const bool again = have && (tracing || c.sh_valid);
     // no ray, not dead: the item it took lies outside a ragged frame edge; it takes the next one in another pass (class "path ends")
     const bool retry = have && !again && !c.dead;
-    if (again || retry) wf_store_ctx<AOVS>(ctx, stride, id, c, tracing);
+    if (again || retry) wf_store_ctx<AOVS>(ctx, id, c, tracing);
     wf_push(Q, rings, 0, again, id, cap);
     wf_push(Q, rings, 1, retry, id, cap);
     const uint32_t retired = (uint32_t)__popcll(__ballot(have && !again && !retry)); // no ray and no item left: the context is finished
@@ -340,18 +333,15 @@ __global__ void __launch_bounds__(BLOCK, 1) hjr_wavefront_kernel(const KParams P
     const uint32_t cap = P.wf_cap;
     // all contexts start in SHADE queue 1 (class "path ends") with every flag clear: their first pass does nothing but take an item
     for (uint32_t i = threadIdx.x; i < HJR_WF_QUEUES * cap; i += BLOCK) rings[i] = (i >= cap && i < 2u * cap) ? (uint16_t)(i - cap + 1u) : (uint16_t)0;
-    if (threadIdx.x < HJR_WF_QUEUES) { Q->head[threadIdx.x] = 0u; Q->tail[threadIdx.x] = threadIdx.x == 1u ? cap : 0u; Q->count[threadIdx.x] = threadIdx.x == 1u ? cap : 0u; }
+    if (threadIdx.x < HJR_WF_QUEUES) { Q->head[threadIdx.x] = 0u; Q->tail[threadIdx.x] = threadIdx.x == 1u ? cap : 0u; Q->commit[threadIdx.x] = threadIdx.x == 1u ? cap : 0u; }
     if (threadIdx.x == 0u) { Q->live = cap; Q->items_held = 0u; }
 #ifdef HJR_WF_WATCHDOG
     if (threadIdx.x == 0u) wf_t0 = __builtin_amdgcn_s_memrealtime();
 #endif
-    float4* ctx = P.wf_ctx + (size_t)blockIdx.x * cap;
-    {
-        const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        const int planes = AOVS ? HJR_WF_PLANES_FULL : HJR_WF_PLANES_LEAN;
-        for (uint32_t i = threadIdx.x; i < cap; i += BLOCK)
-            for (int pl = 0; pl < planes; pl++) ctx[(size_t)pl * P.wf_plane_stride + i] = pl == 1 ? make_float4(0.0f, 0.0f, 0.0f, bits2f(WF_FRESH)) : z;
-    }
+    constexpr int CTXF4 = AOVS ? HJR_WF_CTX_F4_FULL : HJR_WF_CTX_F4_LEAN;
+    float4* ctx = P.wf_ctx + (size_t)blockIdx.x * cap * CTXF4;
+    for (uint32_t i = threadIdx.x; i < cap * CTXF4; i += BLOCK) // every context starts with all flags clear but `fresh`
+        ctx[i] = (i % CTXF4 == 1u) ? make_float4(0.0f, 0.0f, 0.0f, bits2f(WF_FRESH)) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (LDSBVH) stage_scene_in_lds<SE, BLOCK>(P, after_stacks, nodes, tris, mats, lights); // ends with a barrier
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
@@ -360,45 +350,46 @@ __global__ void __launch_bounds__(BLOCK, 1) hjr_wavefront_kernel(const KParams P
     unsigned long long lc[HJR_NSTAT];
     if (STATS) for (int i = 0; i < HJR_NSTAT; i++) lc[i] = 0;
     WaveRange wr; wr.next = wr.end = 0u; wr.exhausted = false; wr.held = &Q->items_held;
-#ifdef HJR_WF_WATCHDOG
-    uint32_t idle_spins = 0;
-#endif
 
     for (;;) {
         // wave-uniform choice of the next batch: a full SHADE batch first (largest class), then TRACE, then whatever is there
         uint32_t pick = 7u; // 0 trace, 1..4 shade class, 6 leave, 7 wait
         if (lane == 0u) {
-            const uint32_t c0 = __hip_atomic_load(&Q->count[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            // published entries per queue (commit is read before head, so the difference can only err on the low side; clamp the rest)
+            auto queued = [&](uint32_t q) {
+                const uint32_t cm = __hip_atomic_load(&Q->commit[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const uint32_t d = cm - __hip_atomic_load(&Q->head[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                return d > 0x7fffffffu ? 0u : d;
+            };
+            const uint32_t c0 = queued(0u);
             uint32_t best = 0u, bq = 1u;
             for (uint32_t q = 1; q < HJR_WF_QUEUES; q++) {
-                const uint32_t cq = __hip_atomic_load(&Q->count[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const uint32_t cq = queued(q);
                 if (cq > best) { best = cq; bq = q; }
             }
             if (best >= 64u) pick = bq;
-            else if (c0 >= (uint32_t)HJR_WF_TRACE_MIN) pick = 0u;
+            else if (c0 >= P.wf_trace_min) pick = 0u;
             else if (best > 0u && best >= c0) pick = bq;
             else if (c0 > 0u) pick = 0u;
             else if (__hip_atomic_load(&Q->live, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) pick = 6u;
         }
         pick = (uint32_t)__builtin_amdgcn_readfirstlane((int)pick);
+#ifdef HJR_WF_WATCHDOG
+        if (pick != 6u && WF_EXPIRED(6)) { // diagnostic build: record the queue state of the first workgroup that runs out of time
+            if (lane == 0u && atomicAdd(&P.stats[HJR_NSTAT], 1ull) == 0ull) {
+                for (int q = 0; q < HJR_WF_QUEUES; q++) { P.stats[HJR_NSTAT + 1 + q] = Q->commit[q]; P.stats[HJR_NSTAT + 6 + q] = Q->head[q]; P.stats[HJR_NSTAT + 11 + q] = Q->tail[q]; }
+                P.stats[HJR_NSTAT + 16] = Q->live; P.stats[HJR_NSTAT + 17] = blockIdx.x; P.stats[HJR_NSTAT + 18] = Q->items_held;
+            }
+            break;
+        }
+#endif
         if (pick == 6u) break;
         if (pick == 7u) {
             __builtin_amdgcn_s_sleep(16);
-#ifdef HJR_WF_WATCHDOG
-            if (WF_EXPIRED(3)) { // diagnostic build: a workgroup that waits this long has lost a context; record the queue state and leave
-                if (lane == 0u && atomicAdd(&P.stats[HJR_NSTAT], 1ull) == 0ull) {
-                    for (int q = 0; q < HJR_WF_QUEUES; q++) { P.stats[HJR_NSTAT + 1 + q] = Q->count[q]; P.stats[HJR_NSTAT + 6 + q] = Q->head[q]; P.stats[HJR_NSTAT + 11 + q] = Q->tail[q]; }
-                    P.stats[HJR_NSTAT + 16] = Q->live; P.stats[HJR_NSTAT + 17] = blockIdx.x; P.stats[HJR_NSTAT + 18] = Q->items_held;
-                }
-                break;
-            }
-#endif
             continue;
         }
-#ifdef HJR_WF_WATCHDOG
-        idle_spins = 0;
-#endif
-        if (pick == 0u) wf_trace_stage<STATS, WIDTH, BLOCK, ST>(P, Q, rings, nodes, tris, mats, ctx, stack, lc);
+
+        if (pick == 0u) wf_trace_stage<STATS, WIDTH, BLOCK, CTXF4, ST>(P, Q, rings, nodes, tris, mats, ctx, stack, lc);
         else wf_shade_stage<INTEGRATOR, STATS, AOVS, WIDTH, BLOCK, ST>(P, Q, rings, (int)pick, nodes, tris, mats, lights, ctx, wr, stack, lc);
     }
 

@@ -52,6 +52,8 @@ bool load_render_option(const std::string& path, hjr_render_option& o, std::stri
     o.camera_animation_id = -1;
     o.seed = 1;
     o.integrator = HJR_INTEGRATOR_NEE;
+    o.devices = 1;
+    o.tile = 8;
     std::string text;
     if (!read_file(path, text)) { err = "File " + path + " not found"; return false; }
     try {
@@ -116,6 +118,13 @@ bool load_render_option(const std::string& path, hjr_render_option& o, std::stri
             o.seed = (uint32_t)h->number_or("seed", 1);
             std::string in = h->string_or("integrator", "NEE");
             o.integrator = in == "MIS" ? HJR_INTEGRATOR_MIS : (in == "Pathtrace" ? HJR_INTEGRATOR_PT : HJR_INTEGRATOR_NEE);
+            // devices: how many GPUs of the node share a frame (8x8 pixel tiles dealt round-robin, one process per GPU);
+            // tile: the shard granularity, fixed at 8 (one wavefront of pixels) — any other value is rejected rather than ignored
+            const double dv = h->number_or("devices", 1), tl = h->number_or("tile", 8);
+            if (!(dv >= 1 && dv <= 64) || dv != (double)(uint32_t)dv) throw JsonError("Henjou_HIP.devices must be an integer in [1, 64]");
+            if (tl != 8) throw JsonError("Henjou_HIP.tile: only 8 (8x8 pixel tiles) is supported");
+            o.devices = (uint32_t)dv;
+            o.tile = 8;
         }
     } catch (std::exception& e) { // :222-225
         err = std::string("Caught exception: ") + e.what();

@@ -119,6 +119,8 @@ typedef struct hjr_render_option {
     /* optional "Henjou_HIP" section (ignored by the reference): */
     uint32_t seed;               /* default 1 */
     int32_t integrator;          /* default HJR_INTEGRATOR_NEE */
+    uint32_t devices;            /* default 1: GPUs of the node that share each frame (pixel-tile shard, one process per GPU) */
+    uint32_t tile;               /* shard granularity in pixels; 8 is the only supported value */
 } hjr_render_option;
 
 typedef struct hjr_camera {      /* Params.camera_* (renderer/renderer.h:1187-1191) */

@@ -272,18 +272,25 @@ template <int I, bool S, bool S16> static int launch_lds(hjr_ctx* c, const KPara
     const bool full = kp.aov_albedo || kp.aov_normal || kp.tex_desc || kp.sky_tex;
     return full ? launch_lds2<I, S, S16, true>(c, kp, n_items, st) : launch_lds2<I, S, S16, false>(c, kp, n_items, st);
 }
-// Workgroup-local wavefront kernel (hjr_wavefront.hip.h): one 1024-thread workgroup per CU for every layout
-template <int I, bool S, bool LDS, bool S16, int W, bool A> static int launch_wf2(hjr_ctx* c, const KParams& kp, uint64_t n_items, hipStream_t st)
+// Workgroup-local wavefront kernel (hjr_wavefront.hip.h): one 1024-thread workgroup per CU for every layout.  LDS holds the top of
+// the traversal stacks, the scene tables (LDS layouts), the queue header, the hit slots and the id rings; what is left after the
+// fixed parts decides how many stack entries per lane stay in LDS (the rest overflows to HBM).  Returns -2 when the layout does not fit.
+template <int I, bool S, bool LDS, int W, bool A> static int launch_wf2(hjr_ctx* c, const KParams& kp, uint64_t n_items, hipStream_t st)
 {
     uint32_t cap = 2048;
     if (const char* e = getenv("HJR_WF_CAP")) { int v = atoi(e); if (v >= 64 && v <= 32768 && (v & (v - 1)) == 0) cap = (uint32_t)v; }
     uint32_t short_stack = HJR_SHORT_STACK;
     if (const char* e = getenv("HJR_SHORT_STACK")) { int v = atoi(e); if (v >= 1 && v <= 64) short_stack = (uint32_t)v; }
-    const uint32_t lds_entries = LDS ? kp.stack_depth : (kp.stack_depth < short_stack ? kp.stack_depth : short_stack);
     const size_t scene_bytes = LDS ? ((size_t)kp.n_node_f4 + kp.n_tri_f4 + kp.n_mat_f4 + kp.n_light_f4) * 16 : 0;
-    const size_t smem = (((size_t)HJR_BLOCK_LDS * lds_entries * (S16 ? 2 : 4) + 15) / 16) * 16 + scene_bytes + 80 + (size_t)HJR_WF_QUEUES * cap * 2;
-    if (smem > 160u * 1024u) return -2;
-    auto kern = hjr_wavefront_kernel<I, S, HJR_BLOCK_LDS, LDS, S16, W, A>;
+    const size_t fixed = scene_bytes + 96 + (size_t)cap * 12 + (size_t)HJR_WF_QUEUES * cap * 2;
+    const size_t lds_max = 160u * 1024u;
+    if (fixed + (size_t)HJR_BLOCK_LDS * 4 * 4 > lds_max) return -2; // not even four stack entries per lane fit
+    uint32_t lds_entries = (uint32_t)((lds_max - fixed) / ((size_t)HJR_BLOCK_LDS * 4));
+    if (lds_entries > kp.stack_depth) lds_entries = kp.stack_depth;
+    if (!LDS && lds_entries > short_stack) lds_entries = short_stack;
+    if (LDS && getenv("HJR_SHORT_STACK") && lds_entries > short_stack) lds_entries = short_stack;
+    const size_t smem = (size_t)HJR_BLOCK_LDS * lds_entries * 4 + fixed;
+    auto kern = hjr_wavefront_kernel<I, S, HJR_BLOCK_LDS, LDS, W, A>;
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return -1;
     uint64_t blocks = (uint64_t)c->n_cus;
     const uint64_t max_useful = (n_items + cap - 1) / cap;
@@ -301,32 +308,29 @@ template <int I, bool S, bool LDS, bool S16, int W, bool A> static int launch_wf
     }
     k2.wf_ctx = (float4*)c->d_wf_ctx.p;
     k2.stack_lds_entries = lds_entries;
-    if (!LDS) {
-        k2.spill_stride = (uint32_t)(blocks * HJR_BLOCK_LDS);
-        const uint32_t over = kp.stack_depth > lds_entries ? kp.stack_depth - lds_entries : 0u;
-        const size_t spill_bytes = (size_t)k2.spill_stride * (over ? over : 1u) * 4;
-        if (c->d_spill.cap < spill_bytes) {
-            c->d_spill.release();
-            if (hipMalloc(&c->d_spill.p, spill_bytes) != hipSuccess) return -1;
-            c->d_spill.cap = spill_bytes;
-        }
-        k2.stack_spill = (uint32_t*)c->d_spill.p;
-        c->stats.stack_lds_entries = lds_entries;
+    k2.spill_stride = (uint32_t)(blocks * HJR_BLOCK_LDS);
+    const uint32_t over = kp.stack_depth > lds_entries ? kp.stack_depth - lds_entries : 0u;
+    const size_t spill_bytes = (size_t)k2.spill_stride * (over ? over : 1u) * 4;
+    if (c->d_spill.cap < spill_bytes) {
+        c->d_spill.release();
+        if (hipMalloc(&c->d_spill.p, spill_bytes) != hipSuccess) return -1;
+        c->d_spill.cap = spill_bytes;
     }
+    k2.stack_spill = (uint32_t*)c->d_spill.p;
+    c->stats.stack_lds_entries = lds_entries;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(HJR_BLOCK_LDS), smem, st, k2);
     return 0;
 }
-template <int I, bool S, bool LDS, bool S16, int W> static int launch_wf1(hjr_ctx* c, const KParams& kp, uint64_t n_items, hipStream_t st)
+template <int I, bool S, bool LDS, int W> static int launch_wf1(hjr_ctx* c, const KParams& kp, uint64_t n_items, hipStream_t st)
 {
     const bool full = kp.aov_albedo || kp.aov_normal || kp.tex_desc || kp.sky_tex;
-    return full ? launch_wf2<I, S, LDS, S16, W, true>(c, kp, n_items, st) : launch_wf2<I, S, LDS, S16, W, false>(c, kp, n_items, st);
+    return full ? launch_wf2<I, S, LDS, W, true>(c, kp, n_items, st) : launch_wf2<I, S, LDS, W, false>(c, kp, n_items, st);
 }
 template <int I, bool S> static int launch_wf(hjr_ctx* c, const KParams& kp, uint64_t n_items, int lds_mode, hipStream_t st)
 {
-    if (lds_mode == 1) return launch_wf1<I, S, true, false, 2>(c, kp, n_items, st);
-    if (lds_mode == 2) return launch_wf1<I, S, true, true, 2>(c, kp, n_items, st);
-    if (lds_mode == 3) return launch_wf1<I, S, false, false, 2>(c, kp, n_items, st);
-    return launch_wf1<I, S, false, false, 4>(c, kp, n_items, st);
+    if (lds_mode == 1 || lds_mode == 2) return launch_wf1<I, S, true, 2>(c, kp, n_items, st); // BVH2 + tables staged in LDS (stack entries are always 32-bit here)
+    if (lds_mode == 3) return launch_wf1<I, S, false, 2>(c, kp, n_items, st);
+    return launch_wf1<I, S, false, 4>(c, kp, n_items, st);
 }
 template <int I, bool S> static int launch(hjr_ctx* c, const KParams& kp, uint64_t n_items, int lds_mode, hipStream_t st)
 {
@@ -335,12 +339,7 @@ template <int I, bool S> static int launch(hjr_ctx* c, const KParams& kp, uint64
     const bool wf = pe && strcmp(pe, "wf") == 0;
     c->stats.pipeline = wf ? 1u : 0u;
     if (wf) {
-        int lm = lds_mode;
-        if (lm == 1) { // the wavefront kernel keeps its id queues in LDS too: fall back to 16-bit stack entries when the 32-bit ones leave no room
-            const size_t need = (size_t)HJR_BLOCK_LDS * kp.stack_depth * 4 + ((size_t)kp.n_node_f4 + kp.n_tri_f4 + kp.n_mat_f4 + kp.n_light_f4) * 16 + 80 + (size_t)HJR_WF_QUEUES * 2048 * 2 + 64;
-            if (need > HJR_LDS_BUDGET) lm = 2;
-        }
-        const int rc = launch_wf<I, S>(c, kp, n_items, lm, st);
+        const int rc = launch_wf<I, S>(c, kp, n_items, lds_mode, st);
         if (rc != -2) return rc;
         c->stats.pipeline = 0u; // the scene tables + queues do not fit LDS in this layout: megakernel
     }
@@ -560,6 +559,22 @@ static int fetch_stats(hjr_ctx* c, hipStream_t st)
     uint64_t* dst = &c->stats.samples;
     for (int i = 0; i < 10; i++) dst[i] = h[i];
     c->stats.stack_overflow_pushes = h[10];
+#ifdef HJR_WF_TIMING
+    { // diagnostic build only: where the waves of the wavefront kernel spend their clocks
+        unsigned long long d[16];
+        (void)hipMemcpyFromSymbol(d, HIP_SYMBOL(wf_diag), sizeof(d));
+        const double tot = (double)d[0] + (double)d[1] + (double)d[2];
+        if (tot > 0) {
+            fprintf(stderr, "[hjr wf timing] scheduler idle %.1f%%  trace stage %.1f%% (hand-overs %.1f%%)  shade stage %.1f%% (waiting for context loads %.1f%%, store + push %.1f%%)\n",
+                    100 * d[0] / tot, 100 * d[1] / tot, 100 * d[9] / tot, 100 * d[2] / tot, 100 * d[3] / tot, 100 * d[10] / tot);
+            fprintf(stderr, "[hjr wf timing] shade batches %llu, %.1f contexts each; trace calls %llu, hand-overs %llu with %.1f finished rays each\n", d[4], d[4] ? (double)d[5] / d[4] : 0.0,
+                    d[8], d[6], d[6] ? (double)d[7] / d[6] : 0.0);
+            fprintf(stderr, "[hjr wf timing] wf_push %.1f%% of wave time (waiting to publish %.1f%%), %.0f clocks per push; wf_pop %.1f%%\n", 100 * d[11] / tot, 100 * d[12] / tot, d[14] ? (double)d[11] / d[14] : 0.0, 100 * d[13] / tot);
+            unsigned long long z[16] = { 0 };
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(wf_diag), z, sizeof(z));
+        }
+    }
+#endif
 #ifdef HJR_WF_WATCHDOG
     { // diagnostic build only: did the wavefront kernel run into its deadline, and where?
         unsigned long long wd[19];

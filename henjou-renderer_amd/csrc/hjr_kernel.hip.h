@@ -202,10 +202,51 @@ HD void ctx_reset(LaneCtx& c)
 #define HJR_CHUNK(c) ((c).item >> 26)
 #define HJR_S_END(c) min((HJR_CHUNK(c) + 1u) * P.chunk_spp, P.spp)
 
-// this wave's private range of the global work queue (wave-uniform).  `held` (wavefront kernel; null in the megakernel) counts the
-// items that the waves of one workgroup hold in their private ranges: there a context is handed from wave to wave, so one that
-// finds the global queue dry in the hands of a wave with an empty range must not die while another wave still has items for it.
-struct WaveRange { uint32_t next, end; bool exhausted; uint32_t* held; };
+// Where a wave's idle lanes get their work items from.
+//  * megakernel: this wave's PRIVATE range of the global queue (next / end / exhausted, all wave-uniform): 64 items per atomic on
+//    the global head.  A lane stays with its wave, so whatever the wave fetched is consumed by the wave.
+//  * wavefront kernel (`shared` set): contexts wander between the waves of a workgroup, so a private range could strand items with
+//    a wave that no longer meets a context in need.  There the range is SHARED by the workgroup (LDS): claims are 64-bit
+//    compare-and-swaps on a packed (next, end) word, the wave that finds it empty refills it from the global head under a small
+//    lock, and "the global queue is dry and the shared range is empty" is then a fact of the whole workgroup.
+struct SharedRange {
+    unsigned long long range; // next | end << 32
+    uint32_t lock;            // 1 while a wave is fetching the next range
+    uint32_t exhausted;       // the global queue has run dry (set under the lock)
+};
+struct WaveRange { uint32_t next, end; bool exhausted; SharedRange* shared; };
+#ifndef HJR_WF_ITEM_FETCH
+#define HJR_WF_ITEM_FETCH 256u /* items per refill of a workgroup's shared range */
+#endif
+// Claims up to n items of the workgroup's shared range for the calling wave (ONE lane calls this): at most two runs of
+// consecutive items, [a0, a0 + n0) and [a1, a1 + n1).  n0 + n1 < n only when the frame has no more items for this workgroup.
+HD void shared_claim(const KParams& P, SharedRange* S, uint32_t n, uint32_t& a0, uint32_t& n0, uint32_t& a1, uint32_t& n1)
+{
+    a0 = a1 = n0 = n1 = 0u;
+    uint32_t left = n;
+    while (left) {
+        const unsigned long long old = __hip_atomic_load(&S->range, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint32_t nx = (uint32_t)old, en = (uint32_t)(old >> 32);
+        if (en != nx) {
+            const uint32_t take = min(left, en - nx);
+            if (atomicCAS(&S->range, old, (unsigned long long)(nx + take) | ((unsigned long long)en << 32)) != old) continue;
+            if (n0 == 0u) { a0 = nx; n0 = take; } else { a1 = nx; n1 = take; }
+            left -= take;
+            if (n1) break; // two runs are all a caller can take (ranges are HJR_WF_ITEM_FETCH >= 64 items unless the frame ends)
+            continue;
+        }
+        if (__hip_atomic_load(&S->exhausted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+        if (atomicCAS(&S->lock, 0u, 1u) == 0u) { // this wave refills (unless another one just did)
+            const unsigned long long now = __hip_atomic_load(&S->range, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if ((uint32_t)now == (uint32_t)(now >> 32)) {
+                const uint32_t base = atomicAdd(P.queue_head, HJR_WF_ITEM_FETCH);
+                if (base >= P.n_owned_items) __hip_atomic_store(&S->exhausted, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                else __hip_atomic_store(&S->range, (unsigned long long)base | ((unsigned long long)min(base + HJR_WF_ITEM_FETCH, P.n_owned_items) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            __hip_atomic_store(&S->lock, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else __builtin_amdgcn_s_sleep(2);
+    }
+}
 
 // NaN/Inf guard + ordered accumulation of one finished sample
 template <bool STATS> HD void finish_sample(LaneCtx& c, f3 L, unsigned long long* lc)
@@ -280,7 +321,15 @@ HD void bounce_pre_trace(const KParams& P, LaneCtx& c, WaveRange& wr, const bool
         if (m) {
             const uint32_t n = (uint32_t)__popcll(m);
             const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            uint32_t q = wr.next + prefix;          // wave-uniform wr.next / wr.end
+            uint32_t q;
+            if (wr.shared) { // wavefront kernel: the workgroup's shared range
+                uint32_t a0 = 0, n0 = 0, a1 = 0, n1 = 0;
+                if (lane == 0) shared_claim(P, wr.shared, n, a0, n0, a1, n1);
+                a0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)a0); n0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)n0);
+                a1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)a1); n1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)n1);
+                q = prefix < n0 ? a0 + prefix : (prefix - n0 < n1 ? a1 + (prefix - n0) : 0xffffffffu);
+            } else {
+            q = wr.next + prefix;                   // wave-uniform wr.next / wr.end
             const uint32_t have = wr.end - wr.next; // items left in the private range
             if (n > have) {                         // not enough: lanes beyond `have` come from a fresh range
                 // once a wave has seen the queue run dry it never touches the head again (wave-uniform flag): the 32-bit head
@@ -291,17 +340,16 @@ HD void bounce_pre_trace(const KParams& P, LaneCtx& c, WaveRange& wr, const bool
                     base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
                     wr.exhausted = base >= P.n_owned_items;
                 }
-                if (wr.held && have && lane == 0) atomicSub(wr.held, have); // the rest of the old range is handed out now
                 if (wr.exhausted) {
                     if (prefix >= have) q = 0xffffffffu;
                     wr.next = wr.end = 0u;
                 } else {
                     if (prefix >= have) q = base + (prefix - have);
-                    wr.end = min(base + 64u, P.n_owned_items); // a range never reaches past the last item
-                    wr.next = min(base + (n - have), wr.end);
-                    if (wr.held && lane == 0 && wr.end != wr.next) atomicAdd(wr.held, wr.end - wr.next); // what stays unassigned
+                    wr.next = base + (n - have);
+                    wr.end = base + 64u;
                 }
-            } else { wr.next += n; if (wr.held && lane == 0) atomicSub(wr.held, n); }
+            } else wr.next += n;
+            }
             // measured cost of a tile (orders the tiles of the next frame, hjr_cost_hist_kernel): a lane sums the rays of its
             // consecutive items of one tile and flushes when it moves on; lanes leaving the same tile together (the usual
             // case) share one atomic.  All lanes are here (m is wave-uniform), so the shuffles below are well defined.
@@ -334,7 +382,7 @@ HD void bounce_pre_trace(const KParams& P, LaneCtx& c, WaveRange& wr, const bool
                         c.s = chunk * P.chunk_spp;
                         c.sumL = V1(0.0f); c.sumA = V1(0.0f); c.sumN = V1(0.0f);
                     }
-                } else c.dead = !(wr.held && __hip_atomic_load(wr.held, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u); // wavefront: another wave may still hold items
+                } else c.dead = true;
             }
         }
     }
@@ -539,7 +587,7 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
 
     LaneCtx c;
     ctx_reset(c);
-    WaveRange wr; wr.next = wr.end = 0u; wr.exhausted = false; wr.held = nullptr;
+    WaveRange wr; wr.next = wr.end = 0u; wr.exhausted = false; wr.shared = nullptr;
     bool inflight = false;      // carry-over: this lane's traversal continues in the next round (it skips everything else)
     bool tracing = false, occluded = false;
     Hit h;

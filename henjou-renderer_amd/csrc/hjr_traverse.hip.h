@@ -71,15 +71,26 @@ struct LaneStack {
     uint32_t spill_stride;
     int lds_n;
     uint32_t n_over; // COUNT (the counting kernel variant) only: pushes that went to the overflow buffer
+    // The overflow accesses are written as inline assembly with their own wait: the compiler's wait-count pass does not see them, so
+    // it puts no `s_waitcnt vmcnt(0)` at the merge points of the traversal loop for a load that almost never happens (with ordinary
+    // loads every iteration of the LDS-resident node loop waited for whatever else the wave had in flight, e.g. prefetched rays).
+    // A lane only reads back what it stored itself (same wave, same address: returned in order).
     HD void put(int i, uint32_t ref)
     {
         if (!SPILL || i < lds_n) lds[i * BLOCK_] = stack_enc<E>(ref);
-        else { spill[(size_t)(i - lds_n) * spill_stride] = ref; if (COUNT) n_over++; }
+        else {
+            uint32_t* a = spill + (size_t)(i - lds_n) * spill_stride;
+            asm volatile("global_store_dword %0, %1, off" : : "v"(a), "v"(ref) : "memory");
+            if (COUNT) n_over++;
+        }
     }
     HD uint32_t get(int i) const
     {
         if (!SPILL || i < lds_n) return stack_dec(lds[i * BLOCK_]);
-        return spill[(size_t)(i - lds_n) * spill_stride];
+        const uint32_t* a = spill + (size_t)(i - lds_n) * spill_stride;
+        uint32_t r;
+        asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(a) : "memory");
+        return r;
     }
 };
 

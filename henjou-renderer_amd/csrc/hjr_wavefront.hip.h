@@ -29,14 +29,22 @@
 #endif
 #define HJR_WF_QUEUES 5
 
+// LDS-typed pointers: accesses through them are ds_* instructions (lgkmcnt only).  A generic pointer would make them flat_*
+// instructions, which also count in vmcnt and would make every queue operation wait for the trace stage's prefetch loads.
+#define WF_LDS __attribute__((address_space(3)))
+typedef WF_LDS volatile uint16_t* wf_ring_ptr;
+
 // queue header in LDS (after the scene tables); rings of uint16 ids follow it
 struct WfShared {
     uint32_t head[HJR_WF_QUEUES];   // next ring position to take
     uint32_t tail[HJR_WF_QUEUES];   // next ring position to reserve
     uint32_t commit[HJR_WF_QUEUES]; // positions below this are written and may be taken (published in reservation order)
     uint32_t live;                  // contexts not yet retired
-    uint32_t items_held;            // work items sitting unassigned in the private ranges of this workgroup's waves (WaveRange::held)
+    uint32_t _pad;
+    SharedRange items;              // the workgroup's range of the global work queue (hjr_kernel.hip.h)
 };
+
+static_assert(sizeof(WfShared) <= 96, "the kernel reserves 96 bytes of LDS for the queue header");
 
 // context flags word (plane 1 .w)
 #define WF_HAS_ITEM 1u
@@ -64,6 +72,18 @@ HD bool wf_expired(int where)
 #define WF_EXPIRED(w) false
 #endif
 
+#ifdef HJR_WF_TIMING
+// diagnostic build: per-wave sums, flushed to wf_diag[] at the end: [0] scheduler idle clocks, [1] trace-stage clocks, [2] shade-stage clocks,
+// [3] shade: clocks until the context loads have landed, [4] shade batches, [5] contexts in them, [6] trace hand-overs (report + refill), [7] rays handed
+// over, [8] trace stage calls, [9] clocks inside hand-overs, [10] shade: clocks from the first store to the end of the pushes
+__device__ unsigned long long wf_diag[16]; // ... [11] clocks in wf_push (lane 0), [12] of which waiting to publish, [13] clocks in wf_pop, [14] pushes
+#define WF_T(i, expr) tdiag[i] += (expr)
+#define WF_NOW() __builtin_amdgcn_s_memtime()
+#else
+#define WF_T(i, expr)
+#define WF_NOW() 0ull
+#endif
+
 // ---- queue operations.  Every one is called by all 64 lanes of a wave at a wave-uniform point.
 // Protocol: a producer reserves ring positions (tail), writes them, and PUBLISHES them in reservation order (commit); a taker
 // claims published positions (head), so what it claims is always written and a taker never waits.  A slot holds id + 1 and is
@@ -74,6 +94,9 @@ HD bool wf_expired(int where)
 // Claims up to `want` published entries of queue q: returns how many (wave-uniform) and the first ring position.
 HD uint32_t wf_pop(WfShared* Q, int q, uint32_t want, uint32_t& start)
 {
+#ifdef HJR_WF_TIMING
+    const unsigned long long tq0 = __builtin_amdgcn_s_memtime();
+#endif
     uint32_t got = 0, st = 0;
     if ((threadIdx.x & 63u) == 0u && want) {
         uint32_t h = __hip_atomic_load(&Q->head[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -89,37 +112,50 @@ HD uint32_t wf_pop(WfShared* Q, int q, uint32_t want, uint32_t& start)
     start = (uint32_t)__builtin_amdgcn_readfirstlane((int)st);
     got = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
     if (got) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#ifdef HJR_WF_TIMING
+    if ((threadIdx.x & 63u) == 0u) atomicAdd(&wf_diag[13], __builtin_amdgcn_s_memtime() - tq0);
+#endif
     return got;
 }
 // The id at a claimed ring position (always written: see the protocol above); frees the slot.
-HD uint32_t wf_take(uint16_t* rings, int q, uint32_t pos, uint32_t cap)
+HD uint32_t wf_take(wf_ring_ptr rings, int q, uint32_t pos, uint32_t cap)
 {
-    volatile uint16_t* slot = rings + (size_t)q * cap + (pos & (cap - 1u));
+    wf_ring_ptr slot = rings + (q * cap + (pos & (cap - 1u)));
     const uint32_t v = *slot;
     *slot = 0;
     return v - 1u;
 }
 // Appends the ids of the lanes with `flag` to queue q.  Everything the wave wrote before (context planes in memory, ring slots in
 // LDS) is visible to the workgroup before the entries are published.
-HD void wf_push(WfShared* Q, uint16_t* rings, int q, bool flag, uint32_t id, uint32_t cap)
+HD void wf_push(WfShared* Q, wf_ring_ptr rings, int q, bool flag, uint32_t id, uint32_t cap)
 { // (the release fence below also orders this wave's earlier context stores: one wait covers every push of a hand-over)
     const unsigned long long m = __ballot(flag);
     if (m == 0ull) return;
+#ifdef HJR_WF_TIMING
+    const unsigned long long tp0 = __builtin_amdgcn_s_memtime();
+    unsigned long long tp1 = tp0;
+#endif
     const uint32_t n = (uint32_t)__popcll(m);
     const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
     uint32_t pos = 0;
     if ((threadIdx.x & 63u) == 0u) pos = atomicAdd(&Q->tail[q], n);
     pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos);
     if (flag) {
-        volatile uint16_t* slot = rings + (size_t)q * cap + ((pos + prefix) & (cap - 1u));
+        wf_ring_ptr slot = rings + (q * cap + ((pos + prefix) & (cap - 1u)));
         while (*slot != 0) { if (WF_EXPIRED(2)) break; } // the entry of one lap ago is claimed (a ring holds at most wf_cap ids): its taker zeroes it at once
         *slot = (uint16_t)(id + 1u);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+#ifdef HJR_WF_TIMING
+    tp1 = __builtin_amdgcn_s_memtime();
+#endif
     if ((threadIdx.x & 63u) == 0u) {
         while (__hip_atomic_load(&Q->commit[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != pos) { if (WF_EXPIRED(3)) break; } // earlier reservations publish first
         __hip_atomic_store(&Q->commit[q], pos + n, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
+#ifdef HJR_WF_TIMING
+    if ((threadIdx.x & 63u) == 0u) { const unsigned long long tp2 = __builtin_amdgcn_s_memtime(); atomicAdd(&wf_diag[11], tp2 - tp0); atomicAdd(&wf_diag[12], tp2 - tp1); atomicAdd(&wf_diag[14], 1ull); }
+#endif
 }
 
 // ---- context records: one per context id, HJR_WF_CTX_F4_LEAN float4 = 128 bytes = exactly one cache line (the albedo / normal
@@ -167,11 +203,17 @@ template <bool AOVS> HD void wf_load_ctx(const float4* ctx, uint32_t id, LaneCtx
     } else { c.sumA = V1(0.0f); c.sumN = V1(0.0f); }
 }
 
+
+// hit records live in LDS, one per context id ([b1 | b2 | k] arrays of wf_cap dwords): the TRACE -> SHADE hand-over touches no memory
+struct WfHits { WF_LDS float* b1; WF_LDS float* b2; WF_LDS uint32_t* k; };
+
 // ---- TRACE stage: the fused two-ray traversal of the megakernel (hjr_traverse.hip.h::traverse_fused: shadow ray, then the
 // closest-hit ray, "while-while") with lane-level turnover.  phase: 0 shadow ray, 1 closest-hit ray, 2 empty, 3 finished (result
-// not handed over yet).  Returns when no lane has a ray and the TRACE queue is empty.
+// not handed over yet).  A lane also holds the NEXT context's rays (three float4 of its record), loaded one hand-over ahead: when
+// its rays are done it hands the hit over (LDS only) and starts the prefetched context at once; the loads issued for the one after
+// that have a whole traversal to land.  Returns when no lane has a ray, nothing is prefetched and the TRACE queue is empty.
 template <bool STATS, int WIDTH, int BLOCK, int CTXF4, typename ST>
-HD void wf_trace_stage(const KParams& P, WfShared* Q, uint16_t* rings, const float4* nodes, const float4* tris, const float4* mats, float4* ctx, ST& stack, unsigned long long* lc)
+HD void wf_trace_stage(const KParams& P, WfShared* Q, wf_ring_ptr rings, const WfHits& H, const float4* nodes, const float4* tris, const float4* mats, float4* ctx, ST& stack, unsigned long long* lc, unsigned long long* tdiag)
 {
     const uint32_t cap = P.wf_cap;
     const float tmin = 0.001f;
@@ -183,11 +225,16 @@ HD void wf_trace_stage(const KParams& P, WfShared* Q, uint16_t* rings, const flo
     bool b_valid = false, fresh = false, occluded = false;
     Hit hit; hit.prim = 0xffffffffu; hit.t = 1e16f; hit.k = 0; hit.b1 = hit.b2 = 0.0f;
     BoxRay R = box_ray(o, d);
+    bool n_valid = false; // prefetched context
+    uint32_t n_id = 0;
+    float4 n0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), n1 = n0, n2 = n0;
     for (;;) {
         if (WF_EXPIRED(4)) return;
         const uint32_t n_wait = (uint32_t)__popcll(__ballot(phase >= 2));
         if (n_wait >= P.wf_refill || n_wait == 64u) {
-            // ---- hand the finished rays over: hit record -> context plane 7, context id -> the SHADE queue of what was hit
+            const unsigned long long t_h0 = WF_NOW();
+            WF_T(6, 1); WF_T(7, __popcll(__ballot(phase == 3)));
+            // ---- hand the finished rays over: hit record -> LDS slot of the context, context id -> the SHADE queue of what was hit
             const bool fin = phase == 3;
             if (__ballot(fin)) {
                 uint32_t cls = 0;
@@ -199,34 +246,41 @@ HD void wf_trace_stage(const KParams& P, WfShared* Q, uint16_t* rings, const flo
                         const float4 m0 = m[0], m3 = m[3];
                         cls = f2bits(m3.x) != 0 ? 0u : (f2bits(m3.y) != 0 ? 3u : (m0.w > 0.5f ? 2u : 1u)); // light | glass | metallic (msGGX) | Disney
                     }
-                    ctx[(size_t)id * CTXF4 + 7] = make_float4(hit.t, hit.b1, hit.b2, bits2f(kk | (occluded ? 0x80000000u : 0u)));
+                    H.b1[id] = hit.b1; H.b2[id] = hit.b2; H.k[id] = kk | (occluded ? 0x80000000u : 0u);
                 }
                 for (uint32_t q = 0; q < 4u; q++) wf_push(Q, rings, 1 + (int)q, fin && cls == q, id, cap);
                 if (fin) phase = 2;
             }
-            // ---- refill the empty lanes from the TRACE queue
-            const unsigned long long m_idle = __ballot(phase == 2);
+            // ---- empty lanes start their prefetched context (its loads were issued one hand-over ago)
+            if (phase == 2 && n_valid) {
+                const uint32_t flags = f2bits(n1.w);
+                id = n_id;
+                ro = V(n0.x, n0.y, n0.z); db = V(n0.w, n1.x, n1.y); a_tmax = n1.z;
+                b_valid = flags & WF_TRACING; fresh = flags & WF_FRESH;
+                occluded = false;
+                hit.prim = 0xffffffffu; hit.t = 1e16f;
+                phase = (flags & WF_SH_VALID) ? 0 : 1; // a queued context has at least one of the two rays
+                o = (phase == 0 || !fresh) ? ro : cam_o;
+                d = (phase == 0) ? V(n2.x, n2.y, n2.z) : db;
+                R = box_ray(o, d);
+                sp = 0; cur = 0;
+                n_valid = false;
+            }
+            // ---- and every lane without a prefetched context takes one from the TRACE queue
+            const unsigned long long m_need = __ballot(!n_valid);
             uint32_t start = 0;
-            const uint32_t got = wf_pop(Q, 0, (uint32_t)__popcll(m_idle), start);
+            const uint32_t got = wf_pop(Q, 0, (uint32_t)__popcll(m_need), start);
             if (got) {
-                const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(m_idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_idle, 0u));
-                if (phase == 2 && prefix < got) {
-                    id = wf_take(rings, 0, start + prefix, cap);
-                    const float4* cp = ctx + (size_t)id * CTXF4;
-                    const float4 p0 = cp[0], p1 = cp[1], p2 = cp[2];
-                    const uint32_t flags = f2bits(p1.w);
-                    ro = V(p0.x, p0.y, p0.z); db = V(p0.w, p1.x, p1.y); a_tmax = p1.z;
-                    b_valid = flags & WF_TRACING; fresh = flags & WF_FRESH;
-                    occluded = false;
-                    hit.prim = 0xffffffffu; hit.t = 1e16f;
-                    phase = (flags & WF_SH_VALID) ? 0 : 1; // a queued context has at least one of the two rays
-                    o = (phase == 0 || !fresh) ? ro : cam_o;
-                    d = (phase == 0) ? V(p2.x, p2.y, p2.z) : db;
-                    R = box_ray(o, d);
-                    sp = 0; cur = 0;
+                const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(m_need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_need, 0u));
+                if (!n_valid && prefix < got) {
+                    n_id = wf_take(rings, 0, start + prefix, cap);
+                    const float4* cp = ctx + (size_t)n_id * CTXF4;
+                    n0 = cp[0]; n1 = cp[1]; n2 = cp[2];
+                    n_valid = true;
                 }
             }
-            if (__ballot(phase < 2) == 0ull) return;
+            WF_T(9, WF_NOW() - t_h0);
+            if (__ballot(phase < 2 || n_valid) == 0ull) return;
         }
         if (phase < 2) {
             while (!(cur & HJR_LEAF_FLAG)) { // every lane first descends through inner nodes until it holds a leaf (or is out of work) ...
@@ -272,9 +326,10 @@ HD void wf_trace_stage(const KParams& P, WfShared* Q, uint16_t* rings, const flo
 
 // ---- SHADE stage: up to 64 contexts of one class: second half of the bounce just traced, first half of the next one
 template <int INTEGRATOR, bool STATS, bool AOVS, int WIDTH, int BLOCK, typename ST>
-HD void wf_shade_stage(const KParams& P, WfShared* Q, uint16_t* rings, int q, const float4* nodes, const float4* tris, const float4* mats, const float4* lights,
-                       float4* ctx, WaveRange& wr, ST& stack, unsigned long long* lc)
+HD void wf_shade_stage(const KParams& P, WfShared* Q, wf_ring_ptr rings, const WfHits& H, int q, const float4* nodes, const float4* tris, const float4* mats, const float4* lights,
+                       float4* ctx, WaveRange& wr, ST& stack, unsigned long long* lc, unsigned long long* tdiag)
 {
+    const unsigned long long t_s0 = WF_NOW();
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t cap = P.wf_cap;
     uint32_t start = 0;
@@ -290,9 +345,13 @@ HD void wf_shade_stage(const KParams& P, WfShared* Q, uint16_t* rings, int q, co
         id = wf_take(rings, q, start + lane, cap);
         float4 hr;
         wf_load_ctx<AOVS>(ctx, id, c, tracing, hr);
-        const uint32_t kk = f2bits(hr.w);
+#ifdef HJR_WF_TIMING
+        __builtin_amdgcn_s_waitcnt(0x0070); // vmcnt(0): the loads have landed
+        if (lane == 0u) { WF_T(3, WF_NOW() - t_s0); }
+#endif
+        const uint32_t kk = H.k[id];
         Hit h;
-        h.t = hr.x; h.b1 = hr.y; h.b2 = hr.z; h.k = kk & 0x7fffffffu;
+        h.t = 0.0f; h.b1 = H.b1[id]; h.b2 = H.b2[id]; h.k = kk & 0x7fffffffu; // (the hit distance is not an input of the hit program)
         h.prim = (h.k == WF_MISS) ? 0xffffffffu : f2bits(tris[h.k * HJR_TRI_F4 + 2].y);
         bounce_post_trace<INTEGRATOR, STATS, AOVS, WIDTH, BLOCK, ST>(P, nodes, tris, mats, lights, c, tracing, (kk >> 31) != 0u, h, stack, lc);
     }
@@ -301,19 +360,24 @@ HD void wf_shade_stage(const KParams& P, WfShared* Q, uint16_t* rings, int q, co
     const bool again = have && (tracing || c.sh_valid);
     // no ray, not dead: the item it took lies outside a ragged frame edge; it takes the next one in another pass (class "path ends")
     const bool retry = have && !again && !c.dead;
+    const unsigned long long t_st = WF_NOW();
+    WF_T(4, 1); WF_T(5, got);
     if (again || retry) wf_store_ctx<AOVS>(ctx, id, c, tracing);
     wf_push(Q, rings, 0, again, id, cap);
     wf_push(Q, rings, 1, retry, id, cap);
     const uint32_t retired = (uint32_t)__popcll(__ballot(have && !again && !retry)); // no ray and no item left: the context is finished
     if (retired && lane == 0u) atomicSub(&Q->live, retired);
+    WF_T(10, WF_NOW() - t_st);
 }
 
-// Dynamic LDS: [traversal stacks][scene tables when LDSBVH][WfShared][rings: HJR_WF_QUEUES x wf_cap uint16]
-template <int INTEGRATOR, bool STATS, int BLOCK, bool LDSBVH, bool STACK16, int WIDTH, bool AOVS>
+// Dynamic LDS: [traversal stacks: stack_lds_entries x BLOCK uint32][scene tables when LDSBVH][WfShared][hit slots: 3 x wf_cap dwords][rings: HJR_WF_QUEUES x wf_cap uint16]
+template <int INTEGRATOR, bool STATS, int BLOCK, bool LDSBVH, int WIDTH, bool AOVS>
 __global__ void __launch_bounds__(BLOCK, 1) hjr_wavefront_kernel(const KParams P)
 {
-    typedef typename std::conditional<STACK16, uint16_t, uint32_t>::type SE;
-    typedef LaneStack<SE, BLOCK, !LDSBVH, STATS> ST;
+    // traversal stacks: the top P.stack_lds_entries 32-bit entries of a lane in LDS, deeper ones in the HBM overflow buffer — in every
+    // layout, also the LDS-resident one: LDS also has to hold the hit slots and the queues, and pushes past ~8 pending entries are rare
+    typedef uint32_t SE;
+    typedef LaneStack<SE, BLOCK, true, STATS> ST;
     ST stack;
     stack.n_over = 0;
     stack.lds = reinterpret_cast<SE*>(hjr_smem) + threadIdx.x;
@@ -325,16 +389,20 @@ __global__ void __launch_bounds__(BLOCK, 1) hjr_wavefront_kernel(const KParams P
     const float4* tris = P.tri_geom;
     const float4* mats = P.materials;
     const float4* lights = P.lights;
-    const uint32_t stack_entries = LDSBVH ? P.stack_depth : P.stack_lds_entries;
-    float4* after_stacks = hjr_smem + (BLOCK * stack_entries * (uint32_t)sizeof(SE) + 15u) / 16u;
+    float4* after_stacks = hjr_smem + (BLOCK * P.stack_lds_entries * (uint32_t)sizeof(SE) + 15u) / 16u;
     const uint32_t scene_f4 = LDSBVH ? (P.n_node_f4 + P.n_tri_f4 + P.n_mat_f4 + P.n_light_f4) : 0u;
     WfShared* Q = reinterpret_cast<WfShared*>(after_stacks + scene_f4);
-    uint16_t* rings = reinterpret_cast<uint16_t*>(after_stacks + scene_f4 + 5); // the header takes 80 bytes
+    WfHits H;
+    H.b1 = (WF_LDS float*)(after_stacks + scene_f4 + 6); // the header takes 96 bytes
+    H.b2 = H.b1 + P.wf_cap;
+    H.k = (WF_LDS uint32_t*)(H.b2 + P.wf_cap);
+    wf_ring_ptr rings = (wf_ring_ptr)(H.k + P.wf_cap);
     const uint32_t cap = P.wf_cap;
     // all contexts start in SHADE queue 1 (class "path ends") with every flag clear: their first pass does nothing but take an item
     for (uint32_t i = threadIdx.x; i < HJR_WF_QUEUES * cap; i += BLOCK) rings[i] = (i >= cap && i < 2u * cap) ? (uint16_t)(i - cap + 1u) : (uint16_t)0;
+    for (uint32_t i = threadIdx.x; i < cap; i += BLOCK) { H.b1[i] = 0.0f; H.b2[i] = 0.0f; H.k[i] = WF_MISS; }
     if (threadIdx.x < HJR_WF_QUEUES) { Q->head[threadIdx.x] = 0u; Q->tail[threadIdx.x] = threadIdx.x == 1u ? cap : 0u; Q->commit[threadIdx.x] = threadIdx.x == 1u ? cap : 0u; }
-    if (threadIdx.x == 0u) { Q->live = cap; Q->items_held = 0u; }
+    if (threadIdx.x == 0u) { Q->live = cap; Q->items.range = 0ull; Q->items.lock = 0u; Q->items.exhausted = 0u; }
 #ifdef HJR_WF_WATCHDOG
     if (threadIdx.x == 0u) wf_t0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -349,7 +417,12 @@ __global__ void __launch_bounds__(BLOCK, 1) hjr_wavefront_kernel(const KParams P
 
     unsigned long long lc[HJR_NSTAT];
     if (STATS) for (int i = 0; i < HJR_NSTAT; i++) lc[i] = 0;
-    WaveRange wr; wr.next = wr.end = 0u; wr.exhausted = false; wr.held = &Q->items_held;
+    WaveRange wr; wr.next = wr.end = 0u; wr.exhausted = false; wr.shared = &Q->items;
+#ifdef HJR_WF_TIMING
+    unsigned long long tdiag[11] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+#else
+    unsigned long long* tdiag = nullptr;
+#endif
 
     for (;;) {
         // wave-uniform choice of the next batch: a full SHADE batch first (largest class), then TRACE, then whatever is there
@@ -378,20 +451,28 @@ __global__ void __launch_bounds__(BLOCK, 1) hjr_wavefront_kernel(const KParams P
         if (pick != 6u && WF_EXPIRED(6)) { // diagnostic build: record the queue state of the first workgroup that runs out of time
             if (lane == 0u && atomicAdd(&P.stats[HJR_NSTAT], 1ull) == 0ull) {
                 for (int q = 0; q < HJR_WF_QUEUES; q++) { P.stats[HJR_NSTAT + 1 + q] = Q->commit[q]; P.stats[HJR_NSTAT + 6 + q] = Q->head[q]; P.stats[HJR_NSTAT + 11 + q] = Q->tail[q]; }
-                P.stats[HJR_NSTAT + 16] = Q->live; P.stats[HJR_NSTAT + 17] = blockIdx.x; P.stats[HJR_NSTAT + 18] = Q->items_held;
+                P.stats[HJR_NSTAT + 16] = Q->live; P.stats[HJR_NSTAT + 17] = blockIdx.x; P.stats[HJR_NSTAT + 18] = (uint32_t)(Q->items.range >> 32) - (uint32_t)Q->items.range;
             }
             break;
         }
 #endif
         if (pick == 6u) break;
         if (pick == 7u) {
+#ifdef HJR_WF_TIMING
+            const unsigned long long t_i0 = WF_NOW();
+#endif
             __builtin_amdgcn_s_sleep(16);
+            WF_T(0, WF_NOW() - t_i0);
             continue;
         }
+        const unsigned long long t_g0 = WF_NOW();
 
-        if (pick == 0u) wf_trace_stage<STATS, WIDTH, BLOCK, CTXF4, ST>(P, Q, rings, nodes, tris, mats, ctx, stack, lc);
-        else wf_shade_stage<INTEGRATOR, STATS, AOVS, WIDTH, BLOCK, ST>(P, Q, rings, (int)pick, nodes, tris, mats, lights, ctx, wr, stack, lc);
+        if (pick == 0u) { wf_trace_stage<STATS, WIDTH, BLOCK, CTXF4, ST>(P, Q, rings, H, nodes, tris, mats, ctx, stack, lc, tdiag); WF_T(8, 1); WF_T(1, WF_NOW() - t_g0); }
+        else { wf_shade_stage<INTEGRATOR, STATS, AOVS, WIDTH, BLOCK, ST>(P, Q, rings, H, (int)pick, nodes, tris, mats, lights, ctx, wr, stack, lc, tdiag); WF_T(2, WF_NOW() - t_g0); }
     }
+#ifdef HJR_WF_TIMING
+    if (lane == 0u) for (int i = 0; i < 11; i++) atomicAdd(&wf_diag[i], tdiag[i]);
+#endif
 
     if (STATS) {
         lc[10] = stack.n_over;

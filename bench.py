@@ -3,7 +3,8 @@
 
 A step = one pass of the hot path over one frame: the persistent HIP megakernel renders this rank's 8x8 pixel tiles of
 the BASELINE configs[1] workload (bundled cornelbox.gltf, 1920x1080, 256 spp, NEE integrator, synthetic = the bundled
-scene, no external data), and for N > 1 the float4 framebuffer is summed onto rank 0 with one RCCL reduce over xGMI.
+scene, no external data), and for N > 1 the ranks' packed colour tiles (1 / N of the frame each) are gathered onto rank 0 with one RCCL
+collective over xGMI and scattered into the frame there.
 Scene, BVH and all buffers are resident in HBM before the timed region.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--width 1920 --height 1080 --spp 256]
@@ -191,8 +192,8 @@ def main():
     finally:
         os.chdir(cwd)
     frame = r.render_option.start_frame
-    params, t_frame = r.frame_params(frame, rank=rank, world_size=world,
-                                     flags=hjr.FLAG_ZERO_UNOWNED if world > 1 else 0)
+    # N > 1: every rank renders ONLY its 8x8 tiles, packed back to back (HJR_FLAG_PACKED: 1 / N of the frame, no zero fill)
+    params, t_frame = r.frame_params(frame, rank=rank, world_size=world, flags=hjr.FLAG_PACKED if world > 1 else 0)
     m, inv = r.scene.transforms(t_frame)
     r.device.set_transforms(m, inv)
 
@@ -201,13 +202,28 @@ def main():
     fb_normal = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
 
-    def step_full():  # what the reference's launch produces: aov_color + aov_albedo + aov_normal (renderer.h:1222-1224)
-        r.device.render_device(params, fb.data_ptr(), fb_albedo.data_ptr(), fb_normal.data_ptr(), stream)
-        hjr.exchange_framebuffer(fb, dst=0)
+    if world > 1:  # packed AOV buffers: [max owned tiles over the ranks][64][4] (ranks that own one tile fewer leave the last one zero)
+        n_max = hjr.owned_tiles(W, H, 0, world)
+        pk = torch.zeros((n_max, 64, 4), dtype=torch.float32, device="cuda")
+        pk_albedo, pk_normal = torch.zeros_like(pk), torch.zeros_like(pk)
+        out_c, out_a, out_n = pk, pk_albedo, pk_normal
+    else:
+        out_c, out_a, out_n = fb, fb_albedo, fb_normal
 
-    def step_color():  # the lean colour-only instantiation (only aov_color reaches the PNG in Default mode)
-        r.device.render_device(params, fb.data_ptr(), None, None, stream)
-        hjr.exchange_framebuffer(fb, dst=0)
+    def exchange():
+        # the one data-path collective of a frame: RCCL gather of the packed colour tiles onto rank 0 (point-to-point over xGMI, all
+        # peers in parallel), scattered into the row-major frame there.  Albedo / normal stay on their ranks: Default mode only writes
+        # aov_color to the PNG (renderer.h:1281-1302), as in henjou_cli's multi-GPU path.
+        if world > 1:
+            hjr.gather_tiles(pk, W, H, device=r.device, dst=0, frame=fb)
+
+    def step_full():  # what the reference's launch produces: aov_color + aov_albedo + aov_normal (renderer.h:1222-1224)
+        r.device.render_device(params, out_c.data_ptr(), out_a.data_ptr(), out_n.data_ptr(), stream)
+        exchange()
+
+    def step_color():  # colour only (only aov_color reaches the PNG in Default mode)
+        r.device.render_device(params, out_c.data_ptr(), None, None, stream)
+        exchange()
 
     def fence():
         if world > 1:
@@ -229,10 +245,10 @@ def main():
             t = torch.tensor([el], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
-        return el, ms
+        return el, ms, {0: "persistent megakernel", 1: "workgroup-local wavefront kernel"}[r.device.stats()["pipeline"]]
 
-    elapsed_color, kernel_ms_color = timed(step_color)
-    elapsed, kernel_ms = timed(step_full)  # the headline: EXACTLY args.steps steps between the fences
+    elapsed_color, kernel_ms_color, pipe_color = timed(step_color)
+    elapsed, kernel_ms, pipe_full = timed(step_full)  # the headline: EXACTLY args.steps steps between the fences
 
     total_samples = float(W) * H * SPP * args.steps
     value = total_samples / elapsed / 1e6
@@ -246,7 +262,7 @@ def main():
         "ms_per_step": round(elapsed / args.steps * 1e3, 3),
         "aovs": "color+albedo+normal (the reference raygen's outputs)",
         "color_only": {"value": round(total_samples / elapsed_color / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(elapsed_color / args.steps * 1e3, 3),
-                       "kernel_ms_avg": round(sum(kernel_ms_color) / len(kernel_ms_color), 3),
+                       "kernel_ms_avg": round(sum(kernel_ms_color) / len(kernel_ms_color), 3), "pipeline": pipe_color,
                        "note": "same workload, aov_color only (lean kernel instantiation; Default mode writes only this AOV to the PNG)"},
         "higher_is_better": True,
         "scaling": "strong",
@@ -256,15 +272,15 @@ def main():
         "config": {"workload": "%s: %s %dx%d %d spp, %s integrator" % ({"cornell": "BASELINE configs[1]", "thinfilm": "BASELINE configs[2]", "ior15": "BASELINE configs[3]", "stress": "synthetic stress scene"}[args.scene], r.render_option.gltf_name.decode(), W, H, SPP, args.integrator),
                    "scene": args.scene, "triangles": int(r.scene.view.n_triangles),
                    "width": W, "height": H, "spp": SPP, "integrator": args.integrator,
-                   "parallelism": "8x8 pixel tiles round-robin over %d GPU(s)%s" % (world, " + RCCL reduce of the float4 framebuffer" if world > 1 else "")},
+                   "parallelism": "8x8 pixel tiles round-robin over %d GPU(s)%s" % (world, " + RCCL gather of each rank's packed colour tiles onto rank 0" if world > 1 else "")},
     }
 
     if rank == 0:
         # ---- roofline of the dominant (only) kernel: counters from the counting variant at 1/16 of the samples
         sp = hjr.make_params(W, H, max(SPP // 16, 1), params.camera, frame=params.frame, seed=params.seed, integrator=integ,
                              sky=tuple(params.sky), ibl_intensity=params.ibl_intensity, rank=rank, world_size=world,
-                             flags=hjr.FLAG_STATS)
-        r.device.render_device(sp, fb.data_ptr(), None, None, stream)
+                             flags=hjr.FLAG_STATS | (hjr.FLAG_PACKED if world > 1 else 0))
+        r.device.render_device(sp, out_c.data_ptr(), None, None, stream)
         torch.cuda.synchronize()
         st = r.device.stats()
         bps = algorithmic_bytes_per_sample(st, SPP)
@@ -288,6 +304,7 @@ def main():
 
         roof = {"kernel": "hjr render kernels (%s, 3 AOVs)" % args.integrator, "kernel_ms_avg": round(avg_ms, 3),
                 "kernel_Msamples_per_s": round(samples_per_launch / (avg_ms * 1e-3) / 1e6, 3),
+                "pipeline": pipe_full,
                 "algorithmic": {"bytes_per_sample": round(bps, 1), "GBps": round(algorithmic_gbs, 2),
                                 "note": "SURVEY 8d per-visit byte model x measured rate: counts node / triangle reads that LDS and L2 serve, so it is not a roofline",
                                 "per_sample": {k: round(st[k] / max(st["samples"], 1), 3) for k in

@@ -134,7 +134,7 @@ int main(int argc, char** argv)
         else if (positional == 0) { path = argv[i]; positional++; }
         else if (positional == 1) { device = atoi(argv[i]); positional++; }
     }
-    if (rank >= 0) return (world > 1 && id_path) ? run_rank(path, rank, world, id_path) : 2; // a rank process of a multi-GPU render
+    if (rank >= 0) return (world >= 1 && rank < world && id_path) ? run_rank(path, rank, world, id_path) : 2; // a rank process of a multi-GPU render (world 1: the same code path on one GPU)
     if (devices == 0) { // the JSON decides (host-only parse: no GPU is touched here)
         hjr_render_option opt;
         if (hjr_load_render_option(path, &opt) != HJR_OK) { fprintf(stderr, "henjou_cli: error: %s\n", hjr_last_error()); return 1; }

@@ -275,22 +275,9 @@ template <int I, bool S, bool S16> static int launch_lds(hjr_ctx* c, const KPara
 // Workgroup-local wavefront kernel (hjr_wavefront.hip.h): one 1024-thread workgroup per CU for every layout.  LDS holds the top of
 // the traversal stacks, the scene tables (LDS layouts), the queue header, the hit slots and the id rings; what is left after the
 // fixed parts decides how many stack entries per lane stay in LDS (the rest overflows to HBM).  Returns -2 when the layout does not fit.
-template <int I, bool S, bool LDS, int W, bool A> static int launch_wf2(hjr_ctx* c, const KParams& kp, uint64_t n_items, hipStream_t st)
+template <int I, bool S, bool LDS, bool SP, int W, bool A> static int launch_wf3(hjr_ctx* c, const KParams& kp, uint64_t n_items, uint32_t cap, uint32_t lds_entries, size_t smem, hipStream_t st)
 {
-    uint32_t cap = 2048;
-    if (const char* e = getenv("HJR_WF_CAP")) { int v = atoi(e); if (v >= 64 && v <= 32768 && (v & (v - 1)) == 0) cap = (uint32_t)v; }
-    uint32_t short_stack = HJR_SHORT_STACK;
-    if (const char* e = getenv("HJR_SHORT_STACK")) { int v = atoi(e); if (v >= 1 && v <= 64) short_stack = (uint32_t)v; }
-    const size_t scene_bytes = LDS ? ((size_t)kp.n_node_f4 + kp.n_tri_f4 + kp.n_mat_f4 + kp.n_light_f4) * 16 : 0;
-    const size_t fixed = scene_bytes + 96 + (size_t)cap * 12 + (size_t)HJR_WF_QUEUES * cap * 2;
-    const size_t lds_max = 160u * 1024u;
-    if (fixed + (size_t)HJR_BLOCK_LDS * 4 * 4 > lds_max) return -2; // not even four stack entries per lane fit
-    uint32_t lds_entries = (uint32_t)((lds_max - fixed) / ((size_t)HJR_BLOCK_LDS * 4));
-    if (lds_entries > kp.stack_depth) lds_entries = kp.stack_depth;
-    if (!LDS && lds_entries > short_stack) lds_entries = short_stack;
-    if (LDS && getenv("HJR_SHORT_STACK") && lds_entries > short_stack) lds_entries = short_stack;
-    const size_t smem = (size_t)HJR_BLOCK_LDS * lds_entries * 4 + fixed;
-    auto kern = hjr_wavefront_kernel<I, S, HJR_BLOCK_LDS, LDS, W, A>;
+    auto kern = hjr_wavefront_kernel<I, S, HJR_BLOCK_LDS, LDS, SP, W, A>;
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return -1;
     uint64_t blocks = (uint64_t)c->n_cus;
     const uint64_t max_useful = (n_items + cap - 1) / cap;
@@ -321,6 +308,26 @@ template <int I, bool S, bool LDS, int W, bool A> static int launch_wf2(hjr_ctx*
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(HJR_BLOCK_LDS), smem, st, k2);
     return 0;
 }
+// LDS holds the (top of the) traversal stacks, the scene tables (LDS layouts), the queue header and the id rings; what is left after the
+// fixed parts decides how many stack entries per lane stay in LDS.  Returns -2 when the layout does not fit.
+template <int I, bool S, bool LDS, int W, bool A> static int launch_wf2(hjr_ctx* c, const KParams& kp, uint64_t n_items, hipStream_t st)
+{
+    uint32_t cap = 2048;
+    if (const char* e = getenv("HJR_WF_CAP")) { int v = atoi(e); if (v >= 64 && v <= 32768 && (v & (v - 1)) == 0) cap = (uint32_t)v; }
+    uint32_t short_stack = HJR_SHORT_STACK;
+    const bool force_short = getenv("HJR_SHORT_STACK") != nullptr;
+    if (force_short) { int v = atoi(getenv("HJR_SHORT_STACK")); if (v >= 1 && v <= 64) short_stack = (uint32_t)v; }
+    const size_t scene_bytes = LDS ? ((size_t)kp.n_node_f4 + kp.n_tri_f4 + kp.n_mat_f4 + kp.n_light_f4) * 16 : 0;
+    const size_t fixed = scene_bytes + 96 + (size_t)HJR_WF_QUEUES * cap * 2;
+    const size_t lds_max = 160u * 1024u;
+    if (fixed + (size_t)HJR_BLOCK_LDS * 4 * 4 > lds_max) return -2; // not even four stack entries per lane fit
+    uint32_t lds_entries = (uint32_t)((lds_max - fixed) / ((size_t)HJR_BLOCK_LDS * 4));
+    if (lds_entries > kp.stack_depth) lds_entries = kp.stack_depth;
+    if ((!LDS || force_short) && lds_entries > short_stack) lds_entries = short_stack;
+    const size_t smem = (size_t)HJR_BLOCK_LDS * lds_entries * 4 + fixed;
+    if (LDS && lds_entries >= kp.stack_depth) return launch_wf3<I, S, LDS, false, W, A>(c, kp, n_items, cap, lds_entries, smem, st); // whole stacks in LDS
+    return launch_wf3<I, S, LDS, true, W, A>(c, kp, n_items, cap, lds_entries, smem, st);
+}
 template <int I, bool S, bool LDS, int W> static int launch_wf1(hjr_ctx* c, const KParams& kp, uint64_t n_items, hipStream_t st)
 {
     const bool full = kp.aov_albedo || kp.aov_normal || kp.tex_desc || kp.sky_tex;
@@ -334,9 +341,17 @@ template <int I, bool S> static int launch_wf(hjr_ctx* c, const KParams& kp, uin
 }
 template <int I, bool S> static int launch(hjr_ctx* c, const KParams& kp, uint64_t n_items, int lds_mode, hipStream_t st)
 {
-    // HJR_PIPELINE=mega | wf selects the kernel family; both produce the same bits
+    // Two kernel families produce the same bits (hjr_kernel.hip.h / hjr_wavefront.hip.h); which one is faster depends on the launch
+    // (MI355X, bundled scene 1080p x 256 spp, profiles/r02_experiments.md): MIS 197 ms wavefront vs 238 ms megakernel (its two extra rays
+    // per bounce are traced by sorted, full waves), NEE colour-only 131.6 vs 135.1, NEE with albedo / normal AOVs 147.6 vs 137.1 (the
+    // context record grows past one cache line), Pathtrace 104.4 vs 99.2; scenes read from memory: megakernel (278 vs 352 ms on 1 M
+    // triangles).  HJR_PIPELINE=mega | wf overrides the choice.
     const char* pe = getenv("HJR_PIPELINE");
-    const bool wf = pe && strcmp(pe, "wf") == 0;
+    const bool full_variant = kp.aov_albedo || kp.aov_normal || kp.tex_desc || kp.sky_tex;
+    const bool lds_layout = lds_mode == 1 || lds_mode == 2;
+    bool wf = lds_layout && (I == HJR_INTEGRATOR_MIS || (I == HJR_INTEGRATOR_NEE && !full_variant));
+    if (pe && strcmp(pe, "wf") == 0) wf = true;
+    if (pe && strcmp(pe, "mega") == 0) wf = false;
     c->stats.pipeline = wf ? 1u : 0u;
     if (wf) {
         const int rc = launch_wf<I, S>(c, kp, n_items, lds_mode, st);

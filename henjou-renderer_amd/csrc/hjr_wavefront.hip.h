@@ -204,16 +204,13 @@ template <bool AOVS> HD void wf_load_ctx(const float4* ctx, uint32_t id, LaneCtx
 }
 
 
-// hit records live in LDS, one per context id ([b1 | b2 | k] arrays of wf_cap dwords): the TRACE -> SHADE hand-over touches no memory
-struct WfHits { WF_LDS float* b1; WF_LDS float* b2; WF_LDS uint32_t* k; };
-
 // ---- TRACE stage: the fused two-ray traversal of the megakernel (hjr_traverse.hip.h::traverse_fused: shadow ray, then the
 // closest-hit ray, "while-while") with lane-level turnover.  phase: 0 shadow ray, 1 closest-hit ray, 2 empty, 3 finished (result
 // not handed over yet).  A lane also holds the NEXT context's rays (three float4 of its record), loaded one hand-over ahead: when
-// its rays are done it hands the hit over (LDS only) and starts the prefetched context at once; the loads issued for the one after
+// its rays are done it hands the hit over (slot 7 of the context record) and starts the prefetched context at once; the loads issued for the one after
 // that have a whole traversal to land.  Returns when no lane has a ray, nothing is prefetched and the TRACE queue is empty.
 template <bool STATS, int WIDTH, int BLOCK, int CTXF4, typename ST>
-HD void wf_trace_stage(const KParams& P, WfShared* Q, wf_ring_ptr rings, const WfHits& H, const float4* nodes, const float4* tris, const float4* mats, float4* ctx, ST& stack, unsigned long long* lc, unsigned long long* tdiag)
+HD void wf_trace_stage(const KParams& P, WfShared* Q, wf_ring_ptr rings, const float4* nodes, const float4* tris, const float4* mats, float4* ctx, ST& stack, unsigned long long* lc, unsigned long long* tdiag)
 {
     const uint32_t cap = P.wf_cap;
     const float tmin = 0.001f;
@@ -234,7 +231,7 @@ HD void wf_trace_stage(const KParams& P, WfShared* Q, wf_ring_ptr rings, const W
         if (n_wait >= P.wf_refill || n_wait == 64u) {
             const unsigned long long t_h0 = WF_NOW();
             WF_T(6, 1); WF_T(7, __popcll(__ballot(phase == 3)));
-            // ---- hand the finished rays over: hit record -> LDS slot of the context, context id -> the SHADE queue of what was hit
+            // ---- hand the finished rays over: hit record -> slot 7 of the context record, context id -> the SHADE queue of what was hit
             const bool fin = phase == 3;
             if (__ballot(fin)) {
                 uint32_t cls = 0;
@@ -246,7 +243,7 @@ HD void wf_trace_stage(const KParams& P, WfShared* Q, wf_ring_ptr rings, const W
                         const float4 m0 = m[0], m3 = m[3];
                         cls = f2bits(m3.x) != 0 ? 0u : (f2bits(m3.y) != 0 ? 3u : (m0.w > 0.5f ? 2u : 1u)); // light | glass | metallic (msGGX) | Disney
                     }
-                    H.b1[id] = hit.b1; H.b2[id] = hit.b2; H.k[id] = kk | (occluded ? 0x80000000u : 0u);
+                    ctx[(size_t)id * CTXF4 + 7] = make_float4(hit.t, hit.b1, hit.b2, bits2f(kk | (occluded ? 0x80000000u : 0u)));
                 }
                 for (uint32_t q = 0; q < 4u; q++) wf_push(Q, rings, 1 + (int)q, fin && cls == q, id, cap);
                 if (fin) phase = 2;
@@ -326,7 +323,7 @@ HD void wf_trace_stage(const KParams& P, WfShared* Q, wf_ring_ptr rings, const W
 
 // ---- SHADE stage: up to 64 contexts of one class: second half of the bounce just traced, first half of the next one
 template <int INTEGRATOR, bool STATS, bool AOVS, int WIDTH, int BLOCK, typename ST>
-HD void wf_shade_stage(const KParams& P, WfShared* Q, wf_ring_ptr rings, const WfHits& H, int q, const float4* nodes, const float4* tris, const float4* mats, const float4* lights,
+HD void wf_shade_stage(const KParams& P, WfShared* Q, wf_ring_ptr rings, int q, const float4* nodes, const float4* tris, const float4* mats, const float4* lights,
                        float4* ctx, WaveRange& wr, ST& stack, unsigned long long* lc, unsigned long long* tdiag)
 {
     const unsigned long long t_s0 = WF_NOW();
@@ -349,9 +346,9 @@ HD void wf_shade_stage(const KParams& P, WfShared* Q, wf_ring_ptr rings, const W
         __builtin_amdgcn_s_waitcnt(0x0070); // vmcnt(0): the loads have landed
         if (lane == 0u) { WF_T(3, WF_NOW() - t_s0); }
 #endif
-        const uint32_t kk = H.k[id];
+        const uint32_t kk = f2bits(hr.w);
         Hit h;
-        h.t = 0.0f; h.b1 = H.b1[id]; h.b2 = H.b2[id]; h.k = kk & 0x7fffffffu; // (the hit distance is not an input of the hit program)
+        h.t = hr.x; h.b1 = hr.y; h.b2 = hr.z; h.k = kk & 0x7fffffffu;
         h.prim = (h.k == WF_MISS) ? 0xffffffffu : f2bits(tris[h.k * HJR_TRI_F4 + 2].y);
         bounce_post_trace<INTEGRATOR, STATS, AOVS, WIDTH, BLOCK, ST>(P, nodes, tris, mats, lights, c, tracing, (kk >> 31) != 0u, h, stack, lc);
     }
@@ -370,14 +367,14 @@ HD void wf_shade_stage(const KParams& P, WfShared* Q, wf_ring_ptr rings, const W
     WF_T(10, WF_NOW() - t_st);
 }
 
-// Dynamic LDS: [traversal stacks: stack_lds_entries x BLOCK uint32][scene tables when LDSBVH][WfShared][hit slots: 3 x wf_cap dwords][rings: HJR_WF_QUEUES x wf_cap uint16]
-template <int INTEGRATOR, bool STATS, int BLOCK, bool LDSBVH, int WIDTH, bool AOVS>
+// Dynamic LDS: [traversal stacks: stack_lds_entries x BLOCK uint32][scene tables when LDSBVH][WfShared][rings: HJR_WF_QUEUES x wf_cap uint16]
+// SPILL: only the top stack_lds_entries of a lane's traversal stack are in LDS, deeper ones in the HBM overflow buffer (always for the
+// memory layouts; for the LDS-resident layout only when the whole stacks do not fit beside the scene tables and the queues)
+template <int INTEGRATOR, bool STATS, int BLOCK, bool LDSBVH, bool SPILL, int WIDTH, bool AOVS>
 __global__ void __launch_bounds__(BLOCK, 1) hjr_wavefront_kernel(const KParams P)
 {
-    // traversal stacks: the top P.stack_lds_entries 32-bit entries of a lane in LDS, deeper ones in the HBM overflow buffer — in every
-    // layout, also the LDS-resident one: LDS also has to hold the hit slots and the queues, and pushes past ~8 pending entries are rare
     typedef uint32_t SE;
-    typedef LaneStack<SE, BLOCK, true, STATS> ST;
+    typedef LaneStack<SE, BLOCK, SPILL, STATS> ST;
     ST stack;
     stack.n_over = 0;
     stack.lds = reinterpret_cast<SE*>(hjr_smem) + threadIdx.x;
@@ -392,15 +389,10 @@ __global__ void __launch_bounds__(BLOCK, 1) hjr_wavefront_kernel(const KParams P
     float4* after_stacks = hjr_smem + (BLOCK * P.stack_lds_entries * (uint32_t)sizeof(SE) + 15u) / 16u;
     const uint32_t scene_f4 = LDSBVH ? (P.n_node_f4 + P.n_tri_f4 + P.n_mat_f4 + P.n_light_f4) : 0u;
     WfShared* Q = reinterpret_cast<WfShared*>(after_stacks + scene_f4);
-    WfHits H;
-    H.b1 = (WF_LDS float*)(after_stacks + scene_f4 + 6); // the header takes 96 bytes
-    H.b2 = H.b1 + P.wf_cap;
-    H.k = (WF_LDS uint32_t*)(H.b2 + P.wf_cap);
-    wf_ring_ptr rings = (wf_ring_ptr)(H.k + P.wf_cap);
+    wf_ring_ptr rings = (wf_ring_ptr)(after_stacks + scene_f4 + 6); // the header takes 96 bytes
     const uint32_t cap = P.wf_cap;
     // all contexts start in SHADE queue 1 (class "path ends") with every flag clear: their first pass does nothing but take an item
     for (uint32_t i = threadIdx.x; i < HJR_WF_QUEUES * cap; i += BLOCK) rings[i] = (i >= cap && i < 2u * cap) ? (uint16_t)(i - cap + 1u) : (uint16_t)0;
-    for (uint32_t i = threadIdx.x; i < cap; i += BLOCK) { H.b1[i] = 0.0f; H.b2[i] = 0.0f; H.k[i] = WF_MISS; }
     if (threadIdx.x < HJR_WF_QUEUES) { Q->head[threadIdx.x] = 0u; Q->tail[threadIdx.x] = threadIdx.x == 1u ? cap : 0u; Q->commit[threadIdx.x] = threadIdx.x == 1u ? cap : 0u; }
     if (threadIdx.x == 0u) { Q->live = cap; Q->items.range = 0ull; Q->items.lock = 0u; Q->items.exhausted = 0u; }
 #ifdef HJR_WF_WATCHDOG
@@ -409,7 +401,7 @@ __global__ void __launch_bounds__(BLOCK, 1) hjr_wavefront_kernel(const KParams P
     constexpr int CTXF4 = AOVS ? HJR_WF_CTX_F4_FULL : HJR_WF_CTX_F4_LEAN;
     float4* ctx = P.wf_ctx + (size_t)blockIdx.x * cap * CTXF4;
     for (uint32_t i = threadIdx.x; i < cap * CTXF4; i += BLOCK) // every context starts with all flags clear but `fresh`
-        ctx[i] = (i % CTXF4 == 1u) ? make_float4(0.0f, 0.0f, 0.0f, bits2f(WF_FRESH)) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        ctx[i] = (i % CTXF4 == 1u) ? make_float4(0.0f, 0.0f, 0.0f, bits2f(WF_FRESH)) : ((i % CTXF4 == 7u) ? make_float4(0.0f, 0.0f, 0.0f, bits2f(WF_MISS)) : make_float4(0.0f, 0.0f, 0.0f, 0.0f));
     if (LDSBVH) stage_scene_in_lds<SE, BLOCK>(P, after_stacks, nodes, tris, mats, lights); // ends with a barrier
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
@@ -467,8 +459,8 @@ __global__ void __launch_bounds__(BLOCK, 1) hjr_wavefront_kernel(const KParams P
         }
         const unsigned long long t_g0 = WF_NOW();
 
-        if (pick == 0u) { wf_trace_stage<STATS, WIDTH, BLOCK, CTXF4, ST>(P, Q, rings, H, nodes, tris, mats, ctx, stack, lc, tdiag); WF_T(8, 1); WF_T(1, WF_NOW() - t_g0); }
-        else { wf_shade_stage<INTEGRATOR, STATS, AOVS, WIDTH, BLOCK, ST>(P, Q, rings, H, (int)pick, nodes, tris, mats, lights, ctx, wr, stack, lc, tdiag); WF_T(2, WF_NOW() - t_g0); }
+        if (pick == 0u) { wf_trace_stage<STATS, WIDTH, BLOCK, CTXF4, ST>(P, Q, rings, nodes, tris, mats, ctx, stack, lc, tdiag); WF_T(8, 1); WF_T(1, WF_NOW() - t_g0); }
+        else { wf_shade_stage<INTEGRATOR, STATS, AOVS, WIDTH, BLOCK, ST>(P, Q, rings, (int)pick, nodes, tris, mats, lights, ctx, wr, stack, lc, tdiag); WF_T(2, WF_NOW() - t_g0); }
     }
 #ifdef HJR_WF_TIMING
     if (lane == 0u) for (int i = 0; i < 11; i++) atomicAdd(&wf_diag[i], tdiag[i]);

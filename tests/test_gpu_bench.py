@@ -46,4 +46,4 @@ def test_bench_two_rank_rehearsal():
              "--master-port", "29577", "bench.py", "--gpus", "2", "--width", "320", "--height", "200", "--spp", "32", "--steps", "1",
              "--warmup", "1"], env=env)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and "cpu_baseline" not in d
-    assert "reduce" in d["config"]["parallelism"]
+    assert "gather" in d["config"]["parallelism"]

@@ -52,3 +52,27 @@ def test_cli_renders_every_frame(tmp_path):
     # error path: missing config -> non-zero exit, message on stderr
     q = subprocess.run([CLI, "nope.json"], cwd=work, capture_output=True, text=True, timeout=60)
     assert q.returncode != 0 and "not found" in q.stderr
+
+
+def test_cli_rank_process_path_on_one_gpu(tmp_path):
+    """The per-rank code of the multi-GPU launcher (packed tiles -> ncclGather -> hjr_unpack_tiles_device -> PNG) run as a world of
+    one on the box's single GPU: the PNG must be byte-identical to the single-process path's.  (Two ranks need two GPUs: RCCL
+    refuses two ranks on one device; the N > 1 collective itself is rehearsed over gloo in test_distributed_gloo.py and the tile
+    partition by tests/native/tile_shard_test.cpp.)"""
+    work = tmp_path / "run"
+    shutil.copytree(os.path.join(hjr.ASSETS, "Model"), work / "Model")
+    ro = json.load(open(os.path.join(hjr.ASSETS, "render_option_c1.json")))
+    ro["Image"].update(image_width=75, image_height=41, max_spp=12, image_name="a")  # ragged frame: 10 x 6 tiles
+    ro["Animation"].update(start_frame=1, end_frame=2)
+    (work / "render_option.json").write_text(json.dumps(ro))
+    p = subprocess.run([CLI, "render_option.json"], cwd=work, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    single = (work / "a_001.png").read_bytes()
+    ro["Image"]["image_name"] = "b"
+    (work / "render_option.json").write_text(json.dumps(ro))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    q = subprocess.run([CLI, "render_option.json", "--rank", "0", "--world", "1", "--id", str(work / "rccl_id")], cwd=work, capture_output=True,
+                       text=True, timeout=300, env=env)
+    assert q.returncode == 0, q.stdout + q.stderr
+    assert (work / "b_001.png").read_bytes() == single
+    assert "render + gather + assemble" in q.stderr

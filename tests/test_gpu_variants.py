@@ -1,4 +1,4 @@
-"""Every shipped megakernel layout under a bit-exact parity test (VERDICT r01 task 1).
+"""Every shipped kernel layout of both kernel families under a bit-exact parity test (VERDICT r01 task 1).
 
 hjr_device.hip::launch dispatches four layouts (hjr_stats.lds_mode): 0 = BVH4 read from memory, 1 = BVH2 staged in LDS with
 32-bit stack entries, 2 = BVH2 in LDS with 16-bit stack entries, 3 = BVH2 read from memory; the memory-path layouts keep the
@@ -49,10 +49,10 @@ def oracle_frame(scene, key, w, h, spp, integrator):
     return _oracle_cache[k]
 
 
-def check_layout(scene, key, env, expect_mode, w=96, h=64, spp=4, integrators=ALL_INTEGRATORS, expect_overflow=False, pipeline=None):
+def check_layout(scene, key, env, expect_mode, w=96, h=64, spp=4, integrators=ALL_INTEGRATORS, expect_overflow=False, pipeline="mega"):
     """Renders with the knobs set, asserts the layout, compares all AOVs (full variant) and the colour-only (lean) variant."""
     env = dict(env)
-    if pipeline is not None:
+    if pipeline is not None:  # None = let the library choose the kernel family (test_pipeline_selection)
         env["HJR_PIPELINE"] = pipeline
     with knobs(**env):
         d = scene.device()  # host/frame.cpp reads the layout knobs here; the launch reads HJR_SHORT_STACK
@@ -178,3 +178,31 @@ def test_wavefront_statistics_match_the_megakernel(cornell):
     for k in ("samples", "closest_rays", "shadow_rays", "shaded_hits", "light_samples", "nan_samples", "box_tests_closest",
               "tri_tests_closest", "box_tests_shadow", "tri_tests_shadow"):
         assert res["mega"][k] == res[WF][k], (k, res["mega"][k], res[WF][k])
+
+
+def test_pipeline_selection(cornell):
+    """Without HJR_PIPELINE the library picks the kernel family per launch (hjr_device.hip::launch): the wavefront kernels for MIS
+    and for colour-only NEE on LDS-resident scenes, the megakernel otherwise.  Whatever it picks, the bits are the oracle's."""
+    old = os.environ.pop("HJR_PIPELINE", None)
+    try:
+        d = cornell.device()
+        try:
+            def pipe(integ, aovs):
+                d.render(cornell.hjr_params(48, 32, 2, integrator=integ), want_aovs=aovs)
+                return d.stats()["pipeline"]
+            assert pipe(hjr.INTEGRATOR_NEE, False) == 1 and pipe(hjr.INTEGRATOR_NEE, True) == 0
+            assert pipe(hjr.INTEGRATOR_MIS, False) == 1 and pipe(hjr.INTEGRATOR_MIS, True) == 1
+            assert pipe(hjr.INTEGRATOR_PT, False) == 0
+        finally:
+            d.close()
+        check_layout(cornell, "cornell", {}, expect_mode=1, pipeline=None)
+        with knobs(HJR_LDS_BVH=0):
+            d = cornell.device()
+            try:
+                d.render(cornell.hjr_params(48, 32, 2, integrator=hjr.INTEGRATOR_MIS), want_aovs=False)
+                assert d.stats()["pipeline"] == 0  # scenes read from memory stay on the megakernel
+            finally:
+                d.close()
+    finally:
+        if old is not None:
+            os.environ["HJR_PIPELINE"] = old

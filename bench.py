@@ -16,10 +16,11 @@ performs (colour + albedo + normal AOVs, renderer/renderer.h:1222-1224); `color_
 instantiation next to it.  Plus
   "roofline":     the bound is chosen per launch from hardware counters collected IN THIS RUN (rocprofv3 --pmc passes over
                   tools/kbench, the same library and workload, started before this process touches the GPU):
-                    * scene resident in LDS / L2 (measured HBM rate far below peak): bound "valu" — useful fp32 VALU lane
-                      operations (wave instructions x average active lanes, x 2 FLOP) per second against the 157.3 TFLOP/s
-                      vector peak of MI355X_MICROARCH.md; <= 1 by construction;
-                    * otherwise bound "hbm" with the COUNTER bytes (FETCH_SIZE x 2 + WRITE_SIZE) against 8 TB/s.
+                    * "valu": useful fp32 VALU lane operations (wave instructions x average active lanes, x 2 FLOP) per second
+                      against the 157.3 TFLOP/s vector peak of MI355X_MICROARCH.md;
+                    * "hbm": the COUNTER bytes (FETCH_SIZE x 2 + WRITE_SIZE, Infinity-Cache hits included) against 8 TB/s;
+                  whichever fraction is larger is the roof the launch is closer to and becomes `bound` / `frac` (both <= 1 by
+                  construction, both reported under `counters`).
                   SURVEY.md section 8d's algorithmic-bytes figure stays as a side field (it counts reads that LDS serves).
   "cpu_baseline": the CPU oracle (a from-scratch port; the reference has no CPU path) timed on the host cores
 """
@@ -313,11 +314,11 @@ def main():
         if pmc_full is not None:
             v = counters_view(pmc_full, avg_ms)
             hbm_frac = v["hbm_GBps"] / HBM_PEAK_GBS
-            if hbm_frac < 0.05:  # the scene is served by LDS / L2: the vector ALUs are the roof
+            if v["valu_tflops"] / VALU_PEAK_TFLOPS >= hbm_frac:  # the roof the launch is closer to: vector ALUs (scene served by LDS / L2) ...
                 roof.update({"bound": "valu", "achieved": round(v["valu_tflops"], 3), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                              "frac": round(v["valu_tflops"] / VALU_PEAK_TFLOPS, 5),
                              "definition": "SQ_INSTS_VALU x (SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU) active lanes x 2 FLOP per launch / live kernel time, vs the fp32 vector peak"})
-            else:
+            else:  # ... or the memory side (scenes beyond the caches; the wavefront kernels' context traffic)
                 roof.update({"bound": "hbm", "achieved": round(v["hbm_GBps"], 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_frac, 5),
                              "definition": "(FETCH_SIZE x 2 + WRITE_SIZE) counter bytes per launch / live kernel time, vs 8 TB/s (Infinity-Cache hits are counted by FETCH_SIZE)"})
             roof["traffic"] = int(v["hbm_bytes"])

@@ -342,14 +342,14 @@ template <int I, bool S> static int launch_wf(hjr_ctx* c, const KParams& kp, uin
 template <int I, bool S> static int launch(hjr_ctx* c, const KParams& kp, uint64_t n_items, int lds_mode, hipStream_t st)
 {
     // Two kernel families produce the same bits (hjr_kernel.hip.h / hjr_wavefront.hip.h); which one is faster depends on the launch
-    // (MI355X, bundled scene 1080p x 256 spp, profiles/r02_experiments.md): MIS 197 ms wavefront vs 238 ms megakernel (its two extra rays
-    // per bounce are traced by sorted, full waves), NEE colour-only 131.6 vs 135.1, NEE with albedo / normal AOVs 147.6 vs 137.1 (the
-    // context record grows past one cache line), Pathtrace 104.4 vs 99.2; scenes read from memory: megakernel (278 vs 352 ms on 1 M
-    // triangles).  HJR_PIPELINE=mega | wf overrides the choice.
+    // (MI355X, profiles/r02_experiments.md).  Bundled scene (LDS-resident), 1080p x 256 spp: MIS 197 ms wavefront vs 238 ms megakernel (its
+    // two extra rays per bounce are traced by sorted, full waves), NEE colour-only 131.6 vs 135.1, NEE with albedo / normal AOVs 147.6 vs
+    // 137.1 (the context record grows past one cache line), Pathtrace 104.4 vs 99.2.  Scenes read from memory (1 M triangles, 1080p x 64
+    // spp): MIS 519 vs 729 ms, NEE 272.6 vs 275.6 (250 k triangles: 155 vs 147).  HJR_PIPELINE=mega | wf overrides the choice.
     const char* pe = getenv("HJR_PIPELINE");
     const bool full_variant = kp.aov_albedo || kp.aov_normal || kp.tex_desc || kp.sky_tex;
     const bool lds_layout = lds_mode == 1 || lds_mode == 2;
-    bool wf = lds_layout && (I == HJR_INTEGRATOR_MIS || (I == HJR_INTEGRATOR_NEE && !full_variant));
+    bool wf = I == HJR_INTEGRATOR_MIS || (lds_layout && I == HJR_INTEGRATOR_NEE && !full_variant);
     if (pe && strcmp(pe, "wf") == 0) wf = true;
     if (pe && strcmp(pe, "mega") == 0) wf = false;
     c->stats.pipeline = wf ? 1u : 0u;

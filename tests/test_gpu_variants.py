@@ -176,13 +176,13 @@ def test_wavefront_statistics_match_the_megakernel(cornell):
             finally:
                 d.close()
     for k in ("samples", "closest_rays", "shadow_rays", "shaded_hits", "light_samples", "nan_samples", "box_tests_closest",
-              "tri_tests_closest", "box_tests_shadow", "tri_tests_shadow"):
+              "tri_tests_closest", "box_tests_shadow", "tri_tests_shadow"):  # (LDS layout: both families walk the tree in the same order)
         assert res["mega"][k] == res[WF][k], (k, res["mega"][k], res[WF][k])
 
 
 def test_pipeline_selection(cornell):
     """Without HJR_PIPELINE the library picks the kernel family per launch (hjr_device.hip::launch): the wavefront kernels for MIS
-    and for colour-only NEE on LDS-resident scenes, the megakernel otherwise.  Whatever it picks, the bits are the oracle's."""
+    (any layout) and for colour-only NEE on LDS-resident scenes, the megakernel otherwise.  Whatever it picks, the bits are the oracle's."""
     old = os.environ.pop("HJR_PIPELINE", None)
     try:
         d = cornell.device()
@@ -199,8 +199,10 @@ def test_pipeline_selection(cornell):
         with knobs(HJR_LDS_BVH=0):
             d = cornell.device()
             try:
+                d.render(cornell.hjr_params(48, 32, 2, integrator=hjr.INTEGRATOR_NEE), want_aovs=False)
+                assert d.stats()["pipeline"] == 0  # NEE on a scene read from memory stays on the megakernel ...
                 d.render(cornell.hjr_params(48, 32, 2, integrator=hjr.INTEGRATOR_MIS), want_aovs=False)
-                assert d.stats()["pipeline"] == 0  # scenes read from memory stay on the megakernel
+                assert d.stats()["pipeline"] == 1  # ... MIS is faster on the wavefront kernels in every layout
             finally:
                 d.close()
     finally:

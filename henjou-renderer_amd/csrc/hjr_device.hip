@@ -312,7 +312,7 @@ template <int I, bool S, bool LDS, bool SP, int W, bool A> static int launch_wf3
 // fixed parts decides how many stack entries per lane stay in LDS.  Returns -2 when the layout does not fit.
 template <int I, bool S, bool LDS, int W, bool A> static int launch_wf2(hjr_ctx* c, const KParams& kp, uint64_t n_items, hipStream_t st)
 {
-    uint32_t cap = 2048;
+    uint32_t cap = LDS ? 2048 : 4096; // contexts per workgroup: more of them in flight pay when every node comes from memory (1 M triangles: 272 -> 259 ms)
     if (const char* e = getenv("HJR_WF_CAP")) { int v = atoi(e); if (v >= 64 && v <= 32768 && (v & (v - 1)) == 0) cap = (uint32_t)v; }
     uint32_t short_stack = HJR_SHORT_STACK;
     const bool force_short = getenv("HJR_SHORT_STACK") != nullptr;
@@ -345,11 +345,12 @@ template <int I, bool S> static int launch(hjr_ctx* c, const KParams& kp, uint64
     // (MI355X, profiles/r02_experiments.md).  Bundled scene (LDS-resident), 1080p x 256 spp: MIS 197 ms wavefront vs 238 ms megakernel (its
     // two extra rays per bounce are traced by sorted, full waves), NEE colour-only 131.6 vs 135.1, NEE with albedo / normal AOVs 147.6 vs
     // 137.1 (the context record grows past one cache line), Pathtrace 104.4 vs 99.2.  Scenes read from memory (1 M triangles, 1080p x 64
-    // spp): MIS 519 vs 729 ms, NEE 272.6 vs 275.6 (250 k triangles: 155 vs 147).  HJR_PIPELINE=mega | wf overrides the choice.
+    // spp): MIS 519 vs 729 ms, NEE 259 vs 276 (250 k triangles: 144 vs 147).  HJR_PIPELINE=mega | wf overrides the choice.
     const char* pe = getenv("HJR_PIPELINE");
     const bool full_variant = kp.aov_albedo || kp.aov_normal || kp.tex_desc || kp.sky_tex;
     const bool lds_layout = lds_mode == 1 || lds_mode == 2;
-    bool wf = I == HJR_INTEGRATOR_MIS || (lds_layout && I == HJR_INTEGRATOR_NEE && !full_variant);
+    const bool big_scene = !lds_layout && c->frame.n_tris >= 200000u; // NEE, 1 M triangles: 259 (wavefront, 4096 contexts) vs 276 ms; 250 k: 144 vs 147
+    bool wf = I == HJR_INTEGRATOR_MIS || (I == HJR_INTEGRATOR_NEE && ((lds_layout && !full_variant) || big_scene));
     if (pe && strcmp(pe, "wf") == 0) wf = true;
     if (pe && strcmp(pe, "mega") == 0) wf = false;
     c->stats.pipeline = wf ? 1u : 0u;

@@ -74,6 +74,31 @@ HD void hit_program(const KParams& P, const float4* tris, const float4* mats, co
                 prd.surf.metallic = prd.surf.metallic * e.z;
             }
         }
+        // normal map (Material.normal_tex, NonColor, bound at renderer.h:680; the code that sampled it lived in the missing closest-hit
+        // program: build-defined, glTF 2.0 tangent-space semantics).  Tangent frame per triangle from the world-space edges and the uv
+        // deltas, Gram-Schmidt against the normalised shading normal; n = normalize(T nx + B ny + N nz), (nx, ny, nz) = 2 texel - 1.
+        // A triangle without a uv parametrisation (zero uv determinant) keeps its interpolated normal.
+        const int nm_tex = (int)f2bits(m[4].y);
+        if (nm_tex >= 0) {
+            const float tu = s0.w * w0 + s2.w * h.b1 + s3.y * h.b2;
+            const float tv = s1.w * w0 + s3.x * h.b1 + s3.z * h.b2;
+            const f3 e1 = V(g0.w, g1.x, g1.y) - V(g0.x, g0.y, g0.z), e2 = V(g1.z, g1.w, g2.x) - V(g0.x, g0.y, g0.z);
+            const float du1 = s2.w - s0.w, dv1 = s3.x - s1.w, du2 = s3.y - s0.w, dv2 = s3.z - s1.w;
+            const float det = du1 * dv2 - du2 * dv1;
+            if (det != 0.0f) {
+                const float r = 1.0f / det;
+                const f3 tg = (e1 * dv2 - e2 * dv1) * r, bt = (e2 * du1 - e1 * du2) * r;
+                const f3 ns = normalize(prd.normal);
+                const f3 tp = normalize(tg - ns * dot(ns, tg));
+                f3 bp = cross(ns, tp);
+                if (dot(bp, bt) < 0.0f) bp = -bp;
+                const f3 e = tex_fetch(P, nm_tex, tu, tv);
+                const f3 nm = V(2.0f * e.x - 1.0f, 2.0f * e.y - 1.0f, 2.0f * e.z - 1.0f);
+                const f3 mapped = tp * nm.x + bp * nm.y + ns * nm.z;
+                const float l2 = dot(mapped, mapped);
+                if (l2 > 0.0f && l2 - l2 == 0.0f) prd.normal = mapped * (1.0f / sqrtf(l2)); // degenerate frames (NaN / zero) keep the interpolated normal
+            }
+        }
     }
     prd.emission = V(m2.y, m2.z, m2.w);
     prd.is_light = f2bits(m3.x) != 0;

@@ -55,7 +55,7 @@ bool SceneCopy::set(const hjr_scene_view& v, std::string& err)
     }
     for (uint32_t m = 0; m < v.n_materials; m++) {
         const hjr_material& mt = materials[m];
-        if (mt.basecolor_tex >= (int)v.n_textures || mt.metallic_roughness_tex >= (int)v.n_textures) { err = "material texture slot out of range"; return false; }
+        if (mt.basecolor_tex >= (int)v.n_textures || mt.metallic_roughness_tex >= (int)v.n_textures || mt.normal_tex >= (int)v.n_textures) { err = "material texture slot out of range"; return false; }
     }
     return true;
 }

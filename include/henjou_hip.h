@@ -39,7 +39,7 @@ enum { HJR_MODE_DEFAULT = 0, HJR_MODE_DENOISE = 1, HJR_MODE_DENOISE_UPSCALE2X = 
  *                gltfloader.h:1144-1156; G = roughness, B = metallic)
  *   dropped    : specular (float3; no kernel header reads it), clearcoat_tex, bump_tex (bound by the host, read only by the
  *                missing closest-hit program; the clearcoat factor itself is kept)
- * normal_tex / emission_tex are carried for the loader's sake and not sampled (no tangent frame on this path). */
+ * normal_tex is sampled (tangent-space normal map, build-defined frame: DESIGN.md §10); emission_tex is always -1 on the glTF path. */
 typedef struct hjr_material {
     float basecolor[3];
     float metallic;
@@ -54,7 +54,7 @@ typedef struct hjr_material {
     int32_t is_thinfilm;
     int32_t basecolor_tex;   /* texture slot or -1 (Material.base_color_tex, TexType::sRGB, gltfloader.h:1133-1140) */
     int32_t metallic_roughness_tex; /* slot or -1 (metallic_tex == roughness_tex, NonColor, gltfloader.h:1144-1156): G = roughness, B = metallic */
-    int32_t normal_tex;      /* slot or -1; carried, not sampled (no tangent frame on this path) */
+    int32_t normal_tex;      /* slot or -1 (Material.normal_tex, NonColor, gltfloader.h:1168-1175): tangent-space normal map, per-triangle tangent frame (build-defined) */
     int32_t emission_tex;    /* always -1 on the glTF path (gltfloader.h:1159) */
     int32_t _reserved;
 } hjr_material;              /* 80 bytes */

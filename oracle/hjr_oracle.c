@@ -1081,6 +1081,28 @@ static void RayTrace(tctx* T, f3 o, f3 d, float tmin, float tmax, payload* prd)
             prd->roughness = prd->roughness * e[1];
             prd->metallic = prd->metallic * e[2];
         }
+        /* normal map (Material.normal_tex, gltfloader.h:1168-1175, bound at renderer.h:680; build-defined: glTF 2.0 tangent space).
+         * Per-triangle tangent / bitangent from the world-space edges and uv deltas, tangent orthogonalised against the normalised
+         * shading normal, bitangent = cross(N, T) with the sign of the geometric bitangent; n = normalize(T nx + B ny + N nz). */
+        if (m->normal_tex >= 0 && (uint32_t)m->normal_tex < c->sc.n_textures) {
+            const hjo_texture* tx = &c->sc.textures[m->normal_tex];
+            f3 e1 = sub(W->v1, W->v0), e2 = sub(W->v2, W->v0);
+            float du1 = S->t1.x - S->t0.x, dv1 = S->t1.y - S->t0.y, du2 = S->t2.x - S->t0.x, dv2 = S->t2.y - S->t0.y;
+            float det = du1 * dv2 - du2 * dv1;
+            if (det != 0.0f) {
+                float r = 1.0f / det;
+                f3 tg = muls(sub(muls(e1, dv2), muls(e2, dv1)), r), bt = muls(sub(muls(e2, du1), muls(e1, du2)), r);
+                f3 ns = normalize(prd->normal);
+                f3 tp = normalize(sub(tg, muls(ns, dot(ns, tg))));
+                f3 bp = cross(ns, tp);
+                if (dot(bp, bt) < 0.0f) bp = neg(bp);
+                float e[3]; hjo_tex_fetch(tx->rgba8, (int)tx->width, (int)tx->height, tx->srgb, prd->texcoord.x, prd->texcoord.y, e);
+                f3 nm = V(2.0f * e[0] - 1.0f, 2.0f * e[1] - 1.0f, 2.0f * e[2] - 1.0f);
+                f3 mapped = add(add(muls(tp, nm.x), muls(bp, nm.y)), muls(ns, nm.z));
+                float l2 = dot(mapped, mapped);
+                if (l2 > 0.0f && l2 - l2 == 0.0f) prd->normal = muls(mapped, 1.0f / sqrtf(l2));
+            }
+        }
     }
     prd->primitive_id = prim; prd->instance_id = (int)S->inst;
     T->st.shaded_hits++;

@@ -66,3 +66,32 @@ class StressScene(Cornell):
         self.time = f32_time(1, self.opt.fps)
         self.camera = self.scene.camera(self.opt, self.time)
         self.arrays = self.scene.arrays(self.time)
+
+
+def make_normal_mapped_scene(tmp_path):
+    """cornelbox_texture_test.gltf with a generated wavy tangent-space normal map bound to the textured box and to material 0;
+    returns (Cornell, number of materials with a normal map)."""
+    import json
+    import shutil
+    from PIL import Image
+    work = tmp_path / "nm"
+    shutil.copytree(os.path.join(hjr.ASSETS, "Model"), work / "Model")
+    yy, xx = np.mgrid[0:64, 0:64]
+    nx = 0.35 * np.sin(xx * 0.5) * np.cos(yy * 0.3)
+    ny = 0.35 * np.cos(xx * 0.2 + yy * 0.4)
+    nz = np.sqrt(np.maximum(1.0 - nx * nx - ny * ny, 0.0))
+    img = np.stack([(nx * 0.5 + 0.5) * 255, (ny * 0.5 + 0.5) * 255, (nz * 0.5 + 0.5) * 255], -1).round().astype(np.uint8)
+    Image.fromarray(img).save(str(work / "Model" / "test_gltf" / "texture" / "Normal.png"))
+    gpath = work / "Model" / "test_gltf" / "cornelbox_texture_test.gltf"
+    g = json.load(open(gpath))
+    g["images"].append({"uri": "texture/Normal.png"})
+    g["textures"].append({"source": len(g["images"]) - 1})
+    tex_index = len(g["textures"]) - 1
+    mapped = sorted(set([i for i, m in enumerate(g["materials"]) if "baseColorTexture" in m.get("pbrMetallicRoughness", {})] + [0]))
+    for i in mapped:
+        g["materials"][i]["normalTexture"] = {"index": tex_index}
+    json.dump(g, open(gpath, "w"))
+    ro = json.load(open(os.path.join(hjr.ASSETS, "render_option_tex.json")))
+    ro["GLTF_file"]["gltf_filepath"] = str(work / "Model" / "test_gltf") + "/"
+    (work / "render_option.json").write_text(json.dumps(ro))
+    return Cornell(str(work / "render_option.json")), len(mapped)

@@ -1,6 +1,8 @@
 """GPU parity on the other BASELINE.json configurations: thin-film LUT BSDF (configs[2]), negative-IOR glass with
 ior 1.5 (configs[3]), the diffuse/specular-only variant (configs[1] strict reading) and the synthetic many-triangle
 stress scene.  Same bar as test_gpu_parity.py: bit-exact against the oracle's PORTABLE mode."""
+import os
+
 import numpy as np
 import pytest
 
@@ -170,3 +172,19 @@ def test_no_lights_and_black_sky():
             assert (color[..., :3] == 0).all()
     finally:
         d.close()
+
+
+def test_normal_mapped_scene(tmp_path):
+    """Material.normal_tex (gltfloader.h:1168-1175, bound at renderer.h:680): tangent-space normal map sampled in the closest-hit code
+    (build-defined frame: per-triangle tangent from the uv deltas).  A generated wavy normal map on the textured box and on a wall:
+    GPU == oracle bit for bit in both kernel families, and the map changes the picture."""
+    from scene_util import make_normal_mapped_scene
+    from test_gpu_variants import knobs
+    s, n_mapped = make_normal_mapped_scene(tmp_path)
+    assert s.scene.view.n_textures == 2 and sum(int(m["normal_tex"] >= 0) for m in s.arrays["materials"]) == n_mapped
+    for pipe in ("mega", "wf"):
+        with knobs(HJR_PIPELINE=pipe):
+            with_map, _ = check(s, 112, 80, 6)
+            check(s, 64, 48, 3, integrator=hjr.INTEGRATOR_MIS)
+    plain, _ = check(Cornell("render_option_tex.json"), 112, 80, 6)
+    assert not np.array_equal(with_map, plain)

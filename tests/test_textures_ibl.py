@@ -128,3 +128,22 @@ def test_oracle_renders_textured_scene_and_sky():
     a, _, _, _ = ob.OracleScene(arrays, ob.MATH_PORTABLE).render(c.oracle_params(48, 48, 2))
     b, _, _, _ = ob.OracleScene(Cornell().arrays, ob.MATH_PORTABLE).render(c.oracle_params(48, 48, 2))
     assert not np.array_equal(a, b)
+
+
+def test_oracle_normal_map(tmp_path):
+    """Material.normal_tex through the loader (NonColor slot) and the oracle's build-defined tangent-space lookup: the normal AOV of the
+    mapped surfaces changes, the albedo AOV does not, normals stay unit length where a map applies."""
+    from scene_util import make_normal_mapped_scene
+    c, n_mapped = make_normal_mapped_scene(tmp_path)
+    mats = c.arrays["materials"]
+    assert c.scene.view.n_textures == 2 and sum(int(m["normal_tex"] >= 0) for m in mats) == n_mapped
+    slot = int(mats[0]["normal_tex"])
+    assert c.arrays["textures"][slot][1] == 0  # the normal map is a NonColor texture (gltfloader.h:1171)
+    plain = Cornell("render_option_tex.json")
+    a_img, a_alb, a_nrm, st = ob.OracleScene(c.arrays, ob.MATH_PORTABLE).render(c.oracle_params(64, 48, 1))
+    b_img, b_alb, b_nrm, _ = ob.OracleScene(plain.arrays, ob.MATH_PORTABLE).render(plain.oracle_params(64, 48, 1))
+    assert st["nan_samples"] == 0 and np.isfinite(a_img).all()
+    assert np.array_equal(a_alb, b_alb) and not np.array_equal(a_nrm, b_nrm)
+    changed = np.any(a_nrm[..., :3] != b_nrm[..., :3], axis=-1)
+    assert 0.05 < changed.mean() < 0.95
+    assert np.allclose(np.linalg.norm(a_nrm[changed][:, :3], axis=-1), 1.0, atol=1e-5)

@@ -206,6 +206,7 @@ struct LaneCtx {
     uint32_t it_cost;   // closest-hit rays traced for the current item (feeds the measured-cost tile order)
     f3 sumL, sumA, sumN;
     f3 sh_d, sh_contrib; // pending shadow ray: direction and the contribution that is added iff it is unoccluded
+    f3 mis_contrib;      // MIS only: the BSDF-sampled light term of the bounce shaded last, added right after the pending NEE term is resolved
     float sh_tmax;
     // Register diet (the LDS variant runs at 128 VGPRs): pixel and chunk share one word; ps.ro doubles as the origin of the pending
     // shadow ray (a regenerated path starts at the wave-uniform camera position: `fresh`); ps.L keeps the finished path's radiance
@@ -217,7 +218,7 @@ HD void ctx_reset(LaneCtx& c)
     c.has_item = c.dead = c.path_live = c.fin_pending = c.write_pending = c.sh_valid = false;
     c.fresh = true;
     c.item = c.s = c.it_cost = 0u;
-    c.sumL = c.sumA = c.sumN = c.sh_d = c.sh_contrib = V1(0.0f);
+    c.sumL = c.sumA = c.sumN = c.sh_d = c.sh_contrib = c.mis_contrib = V1(0.0f);
     c.sh_tmax = 0.0f;
     c.ps.ro = c.ps.rd = c.ps.thr = c.ps.L = V1(0.0f);
     c.ps.depth = 0; c.ps.rng_depth = 0;
@@ -435,6 +436,7 @@ HD void bounce_post_trace(const KParams& P, const float4* nodes, const float4* t
     if (c.sh_valid) { // `if (!light_shot.is_hit) LTE += ...` (rt.h:245-259), added to the path the shadow ray belongs to
         if (!occluded) ps.L = ps.L + c.sh_contrib; // ps.L is the finished path's radiance while fin_pending
         c.sh_valid = false;
+        if (INTEGRATOR == HJR_INTEGRATOR_MIS_) { ps.L = ps.L + c.mis_contrib; c.mis_contrib = V1(0.0f); } // rt.h:378 first, then :414 / :418
     }
     if (c.fin_pending) {
         finish_sample<STATS>(c, ps.L, lc);
@@ -500,16 +502,10 @@ HD void bounce_post_trace(const KParams& P, const float4* nodes, const float4* t
     }
 
     if (INTEGRATOR == HJR_INTEGRATOR_MIS_) { // BSDF-sampled light hit, rt.h:383-420
-        // MIS adds this term AFTER the NEE term of the same bounce (rt.h:378 then :414/:418); the NEE term is still
-        // pending, so resolve its shadow ray now to keep the order of the float additions
-        if (c.sh_valid) {
-            Hit shh;
-            Counters cn; cn.box = 0; cn.tri = 0;
-            const bool occ = traverse<true, STATS, WIDTH, BLOCK, ST>(nodes, tris, prd.position, c.sh_d, 0.001f, c.sh_tmax, shh, stack, cn);
-            if (STATS) { lc[2] += 1; lc[5] += cn.box; lc[6] += cn.tri; }
-            if (!occ) ps.L = ps.L + c.sh_contrib;
-            c.sh_valid = false;
-        }
+        // MIS adds this term AFTER the NEE term of the same bounce (rt.h:378 then :414/:418).  The NEE term still waits for its shadow
+        // ray, which is traced with the next closest-hit ray like NEE's (one stand-alone traversal per bounce instead of two): the term
+        // computed here is parked in c.mis_contrib and added right behind the NEE term when that is resolved, so the order of the
+        // float additions is the reference's.  Without a pending NEE term (exactly-zero contribution, no lights) it is added at once.
         float pt_pdf = 1.0f; // uninitialised in the reference when msGGX returns early; defined as 1
         f3 local_wi = V(0.0f, 1.0f, 0.0f);
         const f3 brdf = bsdf_sample(P, sf, local_wo, local_wi, pt_pdf, st);
@@ -517,6 +513,8 @@ HD void bounce_post_trace(const KParams& P, const float4* nodes, const float4* t
         const float cosine1 = absdot(wi, n);
         HitInfo lh;
         ray_trace<STATS, AOVS, WIDTH, BLOCK, ST>(P, nodes, tris, mats, prd.position, wi, lh, stack, lc);
+        bool have_term = false;
+        f3 term = V1(0.0f);
         if (lh.is_hit) {
             if (lh.is_light) {
                 const float cosine2 = absdot(-wi, lh.normal);
@@ -540,10 +538,16 @@ HD void bounce_post_trace(const KParams& P, const float4* nodes, const float4* t
                     lp = lp * invG;
                 }
                 const float mis_weight = pt_pdf / (pt_pdf + lp);
-                ps.L = ps.L + ((((ps.thr * mis_weight) * cosine1) * lh.emission) * brdf) / pt_pdf; // rt.h:414
+                term = ((((ps.thr * mis_weight) * cosine1) * lh.emission) * brdf) / pt_pdf; // rt.h:414
+                have_term = true;
             }
         } else {
-            ps.L = ps.L + (((ps.thr * brdf) * cosine1) * lh.emission) / pt_pdf; // rt.h:418
+            term = (((ps.thr * brdf) * cosine1) * lh.emission) / pt_pdf; // rt.h:418
+            have_term = true;
+        }
+        if (have_term) {
+            if (c.sh_valid) c.mis_contrib = term;
+            else ps.L = ps.L + term;
         }
     }
 

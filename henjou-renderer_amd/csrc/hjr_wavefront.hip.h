@@ -161,8 +161,9 @@ HD void wf_push(WfShared* Q, wf_ring_ptr rings, int q, bool flag, uint32_t id, u
 // ---- context records: one per context id, HJR_WF_CTX_F4_LEAN float4 = 128 bytes = exactly one cache line (the albedo / normal
 // variant appends two float4 and pads to 192 bytes).  A stage loads / stores a context with consecutive dwordx4 accesses of ONE
 // line per lane; plane-major arrays (one line per 16-byte access) cost 8x the L2 traffic and ran 1.7x slower.
-//   0: ro.xyz rd.x   1: rd.yz sh_tmax flags   2: sh_d.xyz item   3: thr.xyz s   4: L.xyz it_cost   5: sumL.xyz (depth | rng_depth << 8)
-//   6: sh_contrib.xyz -   7: hit t b1 b2 (k | occluded << 31)   8: sumA.xyz -   9: sumN.xyz -      (8, 9: AOVS variant only)
+//   0: ro.xyz rd.x   1: rd.yz sh_tmax flags   2: sh_d.xyz item   3: thr.xyz s   4: L.xyz mis.x   5: sumL.xyz (depth | rng_depth << 8 | it_cost << 20)
+//   6: sh_contrib.xyz mis.y   7: mis.z | hit b1 b2 (k | occluded << 31)   8: sumA.xyz -   9: sumN.xyz -      (8, 9: AOVS variant only)
+// (mis = LaneCtx::mis_contrib; slot 7 .yzw is written by the TRACE stage, everything else by the SHADE stage)
 #define HJR_WF_CTX_F4_LEAN 8
 #define HJR_WF_CTX_F4_FULL 12
 template <bool AOVS> HD void wf_store_ctx(float4* ctx, uint32_t id, const LaneCtx& c, bool tracing)
@@ -174,9 +175,11 @@ template <bool AOVS> HD void wf_store_ctx(float4* ctx, uint32_t id, const LaneCt
     p[1] = make_float4(c.ps.rd.y, c.ps.rd.z, c.sh_tmax, bits2f(flags));
     p[2] = make_float4(c.sh_d.x, c.sh_d.y, c.sh_d.z, bits2f(c.item));
     p[3] = make_float4(c.ps.thr.x, c.ps.thr.y, c.ps.thr.z, bits2f(c.s));
-    p[4] = make_float4(c.ps.L.x, c.ps.L.y, c.ps.L.z, bits2f(c.it_cost));
-    p[5] = make_float4(c.sumL.x, c.sumL.y, c.sumL.z, bits2f((uint32_t)c.ps.depth | (c.ps.rng_depth << 8)));
-    p[6] = make_float4(c.sh_contrib.x, c.sh_contrib.y, c.sh_contrib.z, 0.0f);
+    p[4] = make_float4(c.ps.L.x, c.ps.L.y, c.ps.L.z, c.mis_contrib.x);
+    // depth <= 10, rng_depth <= ~300 draws per path, it_cost <= 64 samples x 10 rays per item
+    p[5] = make_float4(c.sumL.x, c.sumL.y, c.sumL.z, bits2f(((uint32_t)c.ps.depth & 0xffu) | ((c.ps.rng_depth & 0xfffu) << 8) | ((c.it_cost & 0xfffu) << 20)));
+    p[6] = make_float4(c.sh_contrib.x, c.sh_contrib.y, c.sh_contrib.z, c.mis_contrib.y);
+    reinterpret_cast<float*>(p + 7)[0] = c.mis_contrib.z;
     if (AOVS) {
         p[8] = make_float4(c.sumA.x, c.sumA.y, c.sumA.z, 0.0f);
         p[9] = make_float4(c.sumN.x, c.sumN.y, c.sumN.z, 0.0f);
@@ -194,9 +197,9 @@ template <bool AOVS> HD void wf_load_ctx(const float4* ctx, uint32_t id, LaneCtx
     c.ps.ro = V(a.x, a.y, a.z); c.ps.rd = V(a.w, b.x, b.y); c.sh_tmax = b.z;
     c.sh_d = V(d.x, d.y, d.z); c.item = f2bits(d.w);
     c.ps.thr = V(e.x, e.y, e.z); c.s = f2bits(e.w);
-    c.ps.L = V(f.x, f.y, f.z); c.it_cost = f2bits(f.w);
-    c.sumL = V(g.x, g.y, g.z); c.ps.depth = (int)(f2bits(g.w) & 0xffu); c.ps.rng_depth = f2bits(g.w) >> 8;
-    c.sh_contrib = V(h.x, h.y, h.z);
+    c.ps.L = V(f.x, f.y, f.z);
+    c.sumL = V(g.x, g.y, g.z); c.ps.depth = (int)(f2bits(g.w) & 0xffu); c.ps.rng_depth = (f2bits(g.w) >> 8) & 0xfffu; c.it_cost = f2bits(g.w) >> 20;
+    c.sh_contrib = V(h.x, h.y, h.z); c.mis_contrib = V(f.w, h.w, hitrec.x);
     if (AOVS) {
         const float4 sa = p[8], sn = p[9];
         c.sumA = V(sa.x, sa.y, sa.z); c.sumN = V(sn.x, sn.y, sn.z);
@@ -243,7 +246,8 @@ HD void wf_trace_stage(const KParams& P, WfShared* Q, wf_ring_ptr rings, const f
                         const float4 m0 = m[0], m3 = m[3];
                         cls = f2bits(m3.x) != 0 ? 0u : (f2bits(m3.y) != 0 ? 3u : (m0.w > 0.5f ? 2u : 1u)); // light | glass | metallic (msGGX) | Disney
                     }
-                    ctx[(size_t)id * CTXF4 + 7] = make_float4(hit.t, hit.b1, hit.b2, bits2f(kk | (occluded ? 0x80000000u : 0u)));
+                    float* hp = reinterpret_cast<float*>(ctx + (size_t)id * CTXF4 + 7) + 1; // .x of the slot belongs to the SHADE stage
+                    hp[0] = hit.b1; hp[1] = hit.b2; hp[2] = bits2f(kk | (occluded ? 0x80000000u : 0u));
                 }
                 for (uint32_t q = 0; q < 4u; q++) wf_push(Q, rings, 1 + (int)q, fin && cls == q, id, cap);
                 if (fin) phase = 2;
@@ -398,7 +402,7 @@ HD void wf_shade_stage(const KParams& P, WfShared* Q, wf_ring_ptr rings, int q, 
 #endif
         const uint32_t kk = f2bits(hr.w);
         Hit h;
-        h.t = hr.x; h.b1 = hr.y; h.b2 = hr.z; h.k = kk & 0x7fffffffu;
+        h.t = 0.0f; h.b1 = hr.y; h.b2 = hr.z; h.k = kk & 0x7fffffffu; // (the hit distance is not an input of the hit program)
         h.prim = (h.k == WF_MISS) ? 0xffffffffu : f2bits(tris[h.k * HJR_TRI_F4 + 2].y);
         bounce_post_trace<INTEGRATOR, STATS, AOVS, WIDTH, BLOCK, ST>(P, nodes, tris, mats, lights, c, tracing, (kk >> 31) != 0u, h, stack, lc);
     }

@@ -585,7 +585,6 @@ static int fetch_stats(hjr_ctx* c, hipStream_t st)
                     100 * d[0] / tot, 100 * d[1] / tot, 100 * d[9] / tot, 100 * d[2] / tot, 100 * d[3] / tot, 100 * d[10] / tot);
             fprintf(stderr, "[hjr wf timing] shade batches %llu, %.1f contexts each; trace calls %llu, hand-overs %llu with %.1f finished rays each\n", d[4], d[4] ? (double)d[5] / d[4] : 0.0,
                     d[8], d[6], d[6] ? (double)d[7] / d[6] : 0.0);
-            fprintf(stderr, "[hjr wf timing] wf_push %.1f%% of wave time (waiting to publish %.1f%%), %.0f clocks per push; wf_pop %.1f%%\n", 100 * d[11] / tot, 100 * d[12] / tot, d[14] ? (double)d[11] / d[14] : 0.0, 100 * d[13] / tot);
             unsigned long long z[16] = { 0 };
             (void)hipMemcpyToSymbol(HIP_SYMBOL(wf_diag), z, sizeof(z));
         }

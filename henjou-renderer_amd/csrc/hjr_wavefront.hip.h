@@ -76,7 +76,7 @@ HD bool wf_expired(int where)
 // diagnostic build: per-wave sums, flushed to wf_diag[] at the end: [0] scheduler idle clocks, [1] trace-stage clocks, [2] shade-stage clocks,
 // [3] shade: clocks until the context loads have landed, [4] shade batches, [5] contexts in them, [6] trace hand-overs (report + refill), [7] rays handed
 // over, [8] trace stage calls, [9] clocks inside hand-overs, [10] shade: clocks from the first store to the end of the pushes
-__device__ unsigned long long wf_diag[16]; // ... [11] clocks in wf_push (lane 0), [12] of which waiting to publish, [13] clocks in wf_pop, [14] pushes
+__device__ unsigned long long wf_diag[16];
 #define WF_T(i, expr) tdiag[i] += (expr)
 #define WF_NOW() __builtin_amdgcn_s_memtime()
 #else
@@ -94,9 +94,6 @@ __device__ unsigned long long wf_diag[16]; // ... [11] clocks in wf_push (lane 0
 // Claims up to `want` published entries of queue q: returns how many (wave-uniform) and the first ring position.
 HD uint32_t wf_pop(WfShared* Q, int q, uint32_t want, uint32_t& start)
 {
-#ifdef HJR_WF_TIMING
-    const unsigned long long tq0 = __builtin_amdgcn_s_memtime();
-#endif
     uint32_t got = 0, st = 0;
     if ((threadIdx.x & 63u) == 0u && want) {
         uint32_t h = __hip_atomic_load(&Q->head[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -112,9 +109,6 @@ HD uint32_t wf_pop(WfShared* Q, int q, uint32_t want, uint32_t& start)
     start = (uint32_t)__builtin_amdgcn_readfirstlane((int)st);
     got = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
     if (got) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-#ifdef HJR_WF_TIMING
-    if ((threadIdx.x & 63u) == 0u) atomicAdd(&wf_diag[13], __builtin_amdgcn_s_memtime() - tq0);
-#endif
     return got;
 }
 // The id at a claimed ring position (always written: see the protocol above); frees the slot.
@@ -131,10 +125,6 @@ HD void wf_push(WfShared* Q, wf_ring_ptr rings, int q, bool flag, uint32_t id, u
 { // (the release fence below also orders this wave's earlier context stores: one wait covers every push of a hand-over)
     const unsigned long long m = __ballot(flag);
     if (m == 0ull) return;
-#ifdef HJR_WF_TIMING
-    const unsigned long long tp0 = __builtin_amdgcn_s_memtime();
-    unsigned long long tp1 = tp0;
-#endif
     const uint32_t n = (uint32_t)__popcll(m);
     const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
     uint32_t pos = 0;
@@ -146,16 +136,10 @@ HD void wf_push(WfShared* Q, wf_ring_ptr rings, int q, bool flag, uint32_t id, u
         *slot = (uint16_t)(id + 1u);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-#ifdef HJR_WF_TIMING
-    tp1 = __builtin_amdgcn_s_memtime();
-#endif
     if ((threadIdx.x & 63u) == 0u) {
         while (__hip_atomic_load(&Q->commit[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != pos) { if (WF_EXPIRED(3)) break; } // earlier reservations publish first
         __hip_atomic_store(&Q->commit[q], pos + n, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
-#ifdef HJR_WF_TIMING
-    if ((threadIdx.x & 63u) == 0u) { const unsigned long long tp2 = __builtin_amdgcn_s_memtime(); atomicAdd(&wf_diag[11], tp2 - tp0); atomicAdd(&wf_diag[12], tp2 - tp1); atomicAdd(&wf_diag[14], 1ull); }
-#endif
 }
 
 // ---- context records: one per context id, HJR_WF_CTX_F4_LEAN float4 = 128 bytes = exactly one cache line (the albedo / normal

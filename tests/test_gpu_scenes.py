@@ -188,3 +188,28 @@ def test_normal_mapped_scene(tmp_path):
             check(s, 64, 48, 3, integrator=hjr.INTEGRATOR_MIS)
     plain, _ = check(Cornell("render_option_tex.json"), 112, 80, 6)
     assert not np.array_equal(with_map, plain)
+
+
+@pytest.mark.parametrize("pipe", ["mega", "wf"])
+def test_empty_scene_is_all_sky(pipe):
+    """No triangles at all (the frame builder emits a single BVH4 root with four empty slots): every path misses, every pixel is
+    scene_sky_default x IBL_intensity, in both kernel families and for every integrator."""
+    from test_gpu_variants import knobs
+    base = Cornell()
+    a = dict(base.arrays)
+    z = np.zeros(0, np.float32)
+    a.update(vertices=z, normals=z, texcoords=z, indices=np.zeros(0, np.uint32), material_ids=np.zeros(0, np.uint32),
+             prim_offsets=np.zeros(0, np.uint32), light_prim_ids=np.zeros(0, np.uint32), light_prim_emission=z)
+    with knobs(HJR_PIPELINE=pipe):
+        d = hjr.Device(0)
+        try:
+            d.upload_arrays(a)
+            d.set_transforms(np.zeros((0, 12), np.float32), np.zeros((0, 12), np.float32))
+            for integ in (hjr.INTEGRATOR_NEE, hjr.INTEGRATOR_PT, hjr.INTEGRATOR_MIS):
+                color, albedo, normal = d.render(base.hjr_params(40, 24, 9, integrator=integ, sky=(0.25, 0.5, 0.75), ibl_intensity=2.0))
+                assert d.stats()["pipeline"] == {"mega": 0, "wf": 1}[pipe] and d.stats()["n_triangles"] == 0
+                exp = np.float32(9) * np.array([0.5, 1.0, 1.5], np.float32) * np.float32(1.0 / 9.0)  # nine equal samples summed, then x 1/spp
+                assert np.allclose(color[..., :3], exp, rtol=1e-6) and (color[..., 3] == 1).all()
+                assert (albedo[..., :3] == 0).all() and (normal[..., :3] == 0).all()
+        finally:
+            d.close()

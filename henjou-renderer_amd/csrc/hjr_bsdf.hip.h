@@ -231,16 +231,33 @@ HD f3 disney_sample(const KParams& P, const Disney& d, f3 wo, f3& wi, float& pdf
     float select_p = cmj_1d(st);
     float pdf_diffuse = 1.0f, pdf_specular = 1.0f, pdf_clearcoat = 1.0f;
     f2 xi = cmj_2d(st);
-    if (select_p < dw) {
-        wi = d_sampleDiffuse(xi, pdf_diffuse);
-        f3 wm = normalize(wi + wo);
-        pdf_specular = d_getPDFSpecular(d.alpha, wm, wo);
-        pdf_clearcoat = d_getPDFClearcoat(wm, wo);
-    } else if (select_p < dw + sw) {
-        f3 wm = sample_visible_normal(d.alpha, xi, wo);
-        pdf_specular = d_getPDFSpecular(d.alpha, wm, wo);
-        wi = reflect3(-wo, wm);
+    // The reference's three branches (:262-291) repeat most of their work: the azimuth sin / cos, the normalisation of the half
+    // vector and the three lobe pdfs are the same operations on the lane's own (xi, wi, wm) whichever lobe was chosen.  A wave that
+    // holds lanes of both the diffuse and the specular lobe (two thirds / one third for a dielectric) runs those parts once here
+    // instead of once per branch; each lane still executes exactly the reference's operation sequence on its own values.
+    const bool lobe_diffuse = select_p < dw;
+    if (lobe_diffuse || select_p < dw + sw) {
+        const float phi = 2.0f * HJ_PI * (lobe_diffuse ? xi.y : xi.x); // d_sampleDiffuse :32 / sample_visible_normal :68
+        float sp, cp;
+        p_sincos(phi, sp, cp);
+        f3 v; // the half vector before its normalisation
+        if (lobe_diffuse) { // d_sampleDiffuse (:30-38), then wm = normalize(wi + wo)
+            const float theta = 0.5f * p_acos(1.0f - 2.0f * xi.x);
+            float sinTheta, cosTheta;
+            p_sincos(theta, sinTheta, cosTheta);
+            wi = V(cp * sinTheta, cosTheta, sp * sinTheta);
+            v = wi + wo;
+        } else { // sample_visible_normal (:64-80)
+            const f3 strech_wo = normalize(V(wo.x * d.alpha, wo.y, wo.z * d.alpha));
+            const float z = fmaf((1.0f - xi.y), (1.0f + strech_wo.y), -strech_wo.y);
+            const float sinTheta = sqrtf(clampf(1.0f - z * z, 0.0f, 1.0f));
+            const f3 h = V(cp * sinTheta, z, sp * sinTheta) + strech_wo;
+            v = V(h.x * d.alpha, h.y, h.z * d.alpha);
+        }
+        const f3 wm = normalize(v);
+        if (!lobe_diffuse) wi = reflect3(-wo, wm);
         pdf_diffuse = d_getPDFDiffuse(wi);
+        pdf_specular = d_getPDFSpecular(d.alpha, wm, wo);
         pdf_clearcoat = d_getPDFClearcoat(wm, wo);
     } else {
         f3 wm = d_sampleClearcoat(xi, wo, pdf_clearcoat);

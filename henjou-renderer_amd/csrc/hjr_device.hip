@@ -284,8 +284,9 @@ template <int I, bool S, bool LDS, bool SP, int W, bool A> static int launch_wf3
     if (blocks > max_useful) blocks = max_useful ? max_useful : 1;
     KParams k2 = kp;
     k2.wf_cap = cap;
-    k2.wf_refill = HJR_WF_REFILL; k2.wf_trace_min = HJR_WF_TRACE_MIN;
+    k2.wf_refill = HJR_WF_REFILL; k2.wf_trace_min = HJR_WF_TRACE_MIN; k2.wf_prefetch_min = HJR_WF_PREFETCH_MIN;
     if (const char* e = getenv("HJR_WF_REFILL")) { int v = atoi(e); if (v >= 1 && v <= 64) k2.wf_refill = (uint32_t)v; }       // tuning knobs
+    if (const char* e = getenv("HJR_WF_PREFETCH_MIN")) { int v = atoi(e); if (v >= 1 && v <= 64) k2.wf_prefetch_min = (uint32_t)v; }
     if (const char* e = getenv("HJR_WF_TRACE_MIN")) { int v = atoi(e); if (v >= 1 && v <= 4096) k2.wf_trace_min = (uint32_t)v; }
     const size_t ctx_bytes = (size_t)(A ? HJR_WF_CTX_F4_FULL : HJR_WF_CTX_F4_LEAN) * 16 * blocks * cap;
     if (c->d_wf_ctx.cap < ctx_bytes) {
@@ -353,6 +354,9 @@ template <int I, bool S> static int launch(hjr_ctx* c, const KParams& kp, uint64
     bool wf = I == HJR_INTEGRATOR_MIS || (I == HJR_INTEGRATOR_NEE && ((lds_layout && !full_variant) || big_scene));
     if (pe && strcmp(pe, "wf") == 0) wf = true;
     if (pe && strcmp(pe, "mega") == 0) wf = false;
+    // the wavefront kernel's queue positions are free-running 32-bit counters per workgroup (hjr_wavefront.hip.h::WfShared): a context is
+    // queued at most ~12 times per sample; frames that could bring one workgroup near 2^32 pushes (4x its even share) stay with the megakernel
+    if ((double)n_items * kp.chunk_spp * 12.0 * 4.0 / (double)(c->n_cus > 0 ? c->n_cus : 1) >= 4.0e9) wf = false;
     c->stats.pipeline = wf ? 1u : 0u;
     if (wf) {
         const int rc = launch_wf<I, S>(c, kp, n_items, lds_mode, st);
@@ -577,7 +581,7 @@ static int fetch_stats(hjr_ctx* c, hipStream_t st)
     c->stats.stack_overflow_pushes = h[10];
 #ifdef HJR_WF_TIMING
     { // diagnostic build only: where the waves of the wavefront kernel spend their clocks
-        unsigned long long d[16];
+        unsigned long long d[24];
         (void)hipMemcpyFromSymbol(d, HIP_SYMBOL(wf_diag), sizeof(d));
         const double tot = (double)d[0] + (double)d[1] + (double)d[2];
         if (tot > 0) {
@@ -585,7 +589,9 @@ static int fetch_stats(hjr_ctx* c, hipStream_t st)
                     100 * d[0] / tot, 100 * d[1] / tot, 100 * d[9] / tot, 100 * d[2] / tot, 100 * d[3] / tot, 100 * d[10] / tot);
             fprintf(stderr, "[hjr wf timing] shade batches %llu, %.1f contexts each; trace calls %llu, hand-overs %llu with %.1f finished rays each\n", d[4], d[4] ? (double)d[5] / d[4] : 0.0,
                     d[8], d[6], d[6] ? (double)d[7] / d[6] : 0.0);
-            unsigned long long z[16] = { 0 };
+            fprintf(stderr, "[hjr wf timing] trace stage lanes: outer iterations %llu with %.1f lanes holding a ray; node steps %llu wave-iterations x %.1f lanes; triangle tests %llu x %.1f lanes\n",
+                    d[15], d[15] ? (double)d[16] / d[15] : 0.0, d[11], d[11] ? (double)d[12] / d[11] : 0.0, d[13], d[13] ? (double)d[14] / d[13] : 0.0);
+            unsigned long long z[24] = { 0 };
             (void)hipMemcpyToSymbol(HIP_SYMBOL(wf_diag), z, sizeof(z));
         }
     }

@@ -48,7 +48,8 @@ struct KParams {
     uint32_t stack_lds_entries;      // memory-path kernels: stack entries per lane kept in LDS (the rest overflow to stack_spill)
     float4* wf_ctx;                  // wavefront kernel: context records, [workgroup][wf_cap] x 128 (192) bytes (hjr_wavefront.hip.h)
     uint32_t wf_cap;                 // contexts per workgroup (power of two, <= 32768: ids travel as uint16 + 1)
-    uint32_t wf_refill, wf_trace_min; // trace-stage turnover threshold (lanes waiting) / scheduler preference for TRACE (queued rays)
+    uint32_t wf_refill, wf_trace_min; // trace-stage hand-over threshold (lanes without a ray) / scheduler preference for TRACE (queued rays)
+    uint32_t wf_prefetch_min;        // trace-stage hand-over threshold (lanes that have used up their prefetched context)
     float4* part_color;              // [n_chunks][owned tile][64] chunk sums when n_chunks > 1
     float4* part_albedo;
     float4* part_normal;

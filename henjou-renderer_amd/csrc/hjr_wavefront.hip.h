@@ -24,6 +24,9 @@
 #ifndef HJR_WF_REFILL
 #define HJR_WF_REFILL 16 /* trace stage: lanes waiting (finished or empty) before the wave stops to report / refill */
 #endif
+#ifndef HJR_WF_PREFETCH_MIN
+#define HJR_WF_PREFETCH_MIN 32 /* trace stage: lanes that have used up their prefetched context before the wave stops for a hand-over */
+#endif
 #ifndef HJR_WF_TRACE_MIN
 #define HJR_WF_TRACE_MIN 32 /* scheduler: a TRACE batch is preferred over a partial SHADE batch from this many queued rays on */
 #endif
@@ -34,14 +37,18 @@
 #define WF_LDS __attribute__((address_space(3)))
 typedef WF_LDS volatile uint16_t* wf_ring_ptr;
 
-// queue header in LDS (after the scene tables); rings of uint16 ids follow it
+// queue header in LDS (after the scene tables); rings of uint16 ids follow it.  Queue 0 (TRACE) has its own 32-bit counters.  The
+// four SHADE queues share two 64-bit words per counter kind: word 0 = queue 1 | queue 2 << 32, word 1 = queue 3 | queue 4 << 32, so
+// that a trace hand-over reserves (and publishes) its entries of two classes with ONE LDS atomic — "path ends" + Disney, which is all
+// most hand-overs carry.  The 32-bit fields are free-running ring positions; a carry from the low into the high field would need 2^32
+// pushes into one queue of one workgroup (hjr_device.hip keeps launches far below that).
 struct WfShared {
-    uint32_t head[HJR_WF_QUEUES];   // next ring position to take
-    uint32_t tail[HJR_WF_QUEUES];   // next ring position to reserve
-    uint32_t commit[HJR_WF_QUEUES]; // positions below this are written and may be taken (published in reservation order)
-    uint32_t live;                  // contexts not yet retired
-    uint32_t _pad;
-    SharedRange items;              // the workgroup's range of the global work queue (hjr_kernel.hip.h)
+    uint32_t head[HJR_WF_QUEUES]; // next ring position to take
+    uint32_t live;                // contexts not yet retired
+    uint32_t tail0, commit0;      // TRACE queue: next position to reserve / positions below this are written and may be taken
+    unsigned long long tail_s[2];   // SHADE queues, packed pairs: next positions to reserve
+    unsigned long long commit_s[2]; // SHADE queues, packed pairs: published positions (in reservation order)
+    SharedRange items;            // the workgroup's range of the global work queue (hjr_kernel.hip.h)
 };
 
 static_assert(sizeof(WfShared) <= 96, "the kernel reserves 96 bytes of LDS for the queue header");
@@ -74,9 +81,10 @@ HD bool wf_expired(int where)
 
 #ifdef HJR_WF_TIMING
 // diagnostic build: per-wave sums, flushed to wf_diag[] at the end: [0] scheduler idle clocks, [1] trace-stage clocks, [2] shade-stage clocks,
+// [11] node-loop wave iterations, [12] lanes active in them, [13] triangle-loop wave iterations, [14] lanes active, [15] outer iterations, [16] lanes with a ray in them, [17] node-loop clocks, [18] leaf clocks
 // [3] shade: clocks until the context loads have landed, [4] shade batches, [5] contexts in them, [6] trace hand-overs (report + refill), [7] rays handed
 // over, [8] trace stage calls, [9] clocks inside hand-overs, [10] shade: clocks from the first store to the end of the pushes
-__device__ unsigned long long wf_diag[16];
+__device__ unsigned long long wf_diag[24];
 #define WF_T(i, expr) tdiag[i] += (expr)
 #define WF_NOW() __builtin_amdgcn_s_memtime()
 #else
@@ -91,6 +99,14 @@ __device__ unsigned long long wf_diag[16];
 // that zero.  Waiting is therefore one-directional — producers wait for takers and for earlier producers, takers for nobody —
 // and cannot deadlock.  (An earlier form let takers claim committed COUNTS and wait for the slot: two producers one lap apart could
 // then write the same slot, and the taker's wave-wide wait loop delayed its clears: lost entries and deadlocks under load.)
+// Published position of queue q (acquire).
+HD uint32_t wf_commit(WfShared* Q, int q, int order)
+{
+    if (q == 0) return order == __ATOMIC_ACQUIRE ? __hip_atomic_load(&Q->commit0, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) : __hip_atomic_load(&Q->commit0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const unsigned long long w = order == __ATOMIC_ACQUIRE ? __hip_atomic_load(&Q->commit_s[(q - 1) >> 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)
+                                                           : __hip_atomic_load(&Q->commit_s[(q - 1) >> 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return (uint32_t)(w >> (((q - 1) & 1) * 32));
+}
 // Claims up to `want` published entries of queue q: returns how many (wave-uniform) and the first ring position.
 HD uint32_t wf_pop(WfShared* Q, int q, uint32_t want, uint32_t& start)
 {
@@ -98,8 +114,8 @@ HD uint32_t wf_pop(WfShared* Q, int q, uint32_t want, uint32_t& start)
     if ((threadIdx.x & 63u) == 0u && want) {
         uint32_t h = __hip_atomic_load(&Q->head[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         for (;;) {
-            const uint32_t avail = __hip_atomic_load(&Q->commit[q], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) - h;
-            if (avail == 0u || avail > 0x7fffffffu || WF_EXPIRED(5)) break; // (a head read before a concurrent claim can be ahead of this commit)
+            const uint32_t avail = wf_commit(Q, q, __ATOMIC_ACQUIRE) - h;
+            if (avail == 0u || avail > 0x7fffffffu || WF_EXPIRED(5)) break;
             const uint32_t take = avail < want ? avail : want;
             const uint32_t old = atomicCAS(&Q->head[q], h, h + take);
             if (old == h) { got = take; st = h; break; }
@@ -119,26 +135,67 @@ HD uint32_t wf_take(wf_ring_ptr rings, int q, uint32_t pos, uint32_t cap)
     *slot = 0;
     return v - 1u;
 }
-// Appends the ids of the lanes with `flag` to queue q.  Everything the wave wrote before (context planes in memory, ring slots in
-// LDS) is visible to the workgroup before the entries are published.
-HD void wf_push(WfShared* Q, wf_ring_ptr rings, int q, bool flag, uint32_t id, uint32_t cap)
-{ // (the release fence below also orders this wave's earlier context stores: one wait covers every push of a hand-over)
+// one ring slot: waits until the entry of one lap ago has been taken (a ring holds at most wf_cap ids: its taker zeroes it at once), then writes
+HD void wf_put(wf_ring_ptr rings, int q, uint32_t pos, uint32_t id, uint32_t cap)
+{
+    wf_ring_ptr slot = rings + (q * cap + (pos & (cap - 1u)));
+    while (*slot != 0) { if (WF_EXPIRED(2)) break; }
+    *slot = (uint16_t)(id + 1u);
+}
+// Appends the ids of the lanes with `flag` to the TRACE queue.  Everything the wave wrote before (context records in memory, ring
+// slots in LDS) is visible to the workgroup before the entries are published.
+HD void wf_push_trace(WfShared* Q, wf_ring_ptr rings, bool flag, uint32_t id, uint32_t cap)
+{
     const unsigned long long m = __ballot(flag);
     if (m == 0ull) return;
     const uint32_t n = (uint32_t)__popcll(m);
     const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
     uint32_t pos = 0;
-    if ((threadIdx.x & 63u) == 0u) pos = atomicAdd(&Q->tail[q], n);
+    if ((threadIdx.x & 63u) == 0u) pos = atomicAdd(&Q->tail0, n);
     pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos);
-    if (flag) {
-        wf_ring_ptr slot = rings + (q * cap + ((pos + prefix) & (cap - 1u)));
-        while (*slot != 0) { if (WF_EXPIRED(2)) break; } // the entry of one lap ago is claimed (a ring holds at most wf_cap ids): its taker zeroes it at once
-        *slot = (uint16_t)(id + 1u);
-    }
+    if (flag) wf_put(rings, 0, pos + prefix, id, cap);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if ((threadIdx.x & 63u) == 0u) {
-        while (__hip_atomic_load(&Q->commit[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != pos) { if (WF_EXPIRED(3)) break; } // earlier reservations publish first
-        __hip_atomic_store(&Q->commit[q], pos + n, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        while (__hip_atomic_load(&Q->commit0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != pos) { if (WF_EXPIRED(3)) break; } // earlier reservations publish first
+        __hip_atomic_store(&Q->commit0, pos + n, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+}
+// Appends up to two entries per lane to the SHADE queues: e = (id + 1) | class << 16, 0 = none.  One reservation and one ordered
+// publication per packed pair of queues that receives anything (see WfShared).
+HD void wf_push_shade(WfShared* Q, wf_ring_ptr rings, uint32_t e0, uint32_t e1, uint32_t cap)
+{
+    if (__ballot(e0 != 0u) == 0ull) return; // (a lane fills e0 first)
+    const uint32_t c0 = e0 >> 16, c1 = e1 >> 16;
+    uint32_t n[4], pre0 = 0, pre1 = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < 4u; q++) {
+        const unsigned long long b0 = __ballot(e0 != 0u && c0 == q), b1 = __ballot(e1 != 0u && c1 == q);
+        const uint32_t n0 = (uint32_t)__popcll(b0);
+        n[q] = n0 + (uint32_t)__popcll(b1);
+        if (c0 == q) pre0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b0, 0u));
+        if (c1 == q) pre1 = n0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, 0u));
+    }
+    const bool lead = (threadIdx.x & 63u) == 0u;
+    uint32_t base[4] = { 0u, 0u, 0u, 0u };
+#pragma unroll
+    for (int w = 0; w < 2; w++) {
+        if (n[2 * w] + n[2 * w + 1] == 0u) continue; // wave-uniform
+        unsigned long long old = 0ull;
+        if (lead) old = atomicAdd(&Q->tail_s[w], (unsigned long long)n[2 * w] | ((unsigned long long)n[2 * w + 1] << 32));
+        base[2 * w] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)old);
+        base[2 * w + 1] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(old >> 32));
+    }
+    if (e0 != 0u) wf_put(rings, 1 + (int)c0, (c0 == 0u ? base[0] : (c0 == 1u ? base[1] : (c0 == 2u ? base[2] : base[3]))) + pre0, (e0 & 0xffffu) - 1u, cap);
+    if (e1 != 0u) wf_put(rings, 1 + (int)c1, (c1 == 0u ? base[0] : (c1 == 1u ? base[1] : (c1 == 2u ? base[2] : base[3]))) + pre1, (e1 & 0xffffu) - 1u, cap);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lead) {
+#pragma unroll
+        for (int w = 0; w < 2; w++) {
+            if (n[2 * w] + n[2 * w + 1] == 0u) continue;
+            const unsigned long long mine = (unsigned long long)base[2 * w] | ((unsigned long long)base[2 * w + 1] << 32);
+            while (__hip_atomic_load(&Q->commit_s[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != mine) { if (WF_EXPIRED(3)) break; } // earlier reservations publish first
+            __hip_atomic_store(&Q->commit_s[w], (unsigned long long)(base[2 * w] + n[2 * w]) | ((unsigned long long)(base[2 * w + 1] + n[2 * w + 1]) << 32), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
     }
 }
 
@@ -192,10 +249,15 @@ template <bool AOVS> HD void wf_load_ctx(const float4* ctx, uint32_t id, LaneCtx
 
 
 // ---- TRACE stage: the fused two-ray traversal of the megakernel (hjr_traverse.hip.h::traverse_fused: shadow ray, then the
-// closest-hit ray, "while-while") with lane-level turnover.  phase: 0 shadow ray, 1 closest-hit ray, 2 empty, 3 finished (result
-// not handed over yet).  A lane also holds the NEXT context's rays (three float4 of its record), loaded one hand-over ahead: when
-// its rays are done it hands the hit over (slot 7 of the context record) and starts the prefetched context at once; the loads issued for the one after
-// that have a whole traversal to land.  Returns when no lane has a ray, nothing is prefetched and the TRACE queue is empty.
+// closest-hit ray, "while-while") with lane-level turnover.  phase: 0 shadow ray, 1 closest-hit ray, 2 no ray.
+// Everything a lane does when its rays are done is LANE-LOCAL: it writes the hit into slot 7 of the context record, notes
+// (context id, class of what was hit) in one of its two `fin` registers, and starts the context it holds prefetched (three float4 of
+// the record, loaded one hand-over ahead) in the same iteration — no queue operation, no other lane involved.  Only the HAND-OVER is a
+// wave-level step: all noted contexts go to the SHADE queues in one packed push (wf_push_shade) and every lane without a prefetched
+// context takes one from the TRACE queue.  It runs when P.wf_prefetch_min lanes have used up their prefetched context (or
+// P.wf_refill lanes have no ray at all), i.e. every few iterations instead of every iteration: rays of the bundled scene last 2.5
+// iterations on average, and with the hand-over in every iteration it was 15 % of the kernel's time (profiles/r02_experiments.md).
+// Returns when no lane has a ray, nothing is prefetched and the TRACE queue is empty.
 template <bool STATS, bool SPECULATE, int WIDTH, int BLOCK, int CTXF4, typename ST>
 HD void wf_trace_stage(const KParams& P, WfShared* Q, wf_ring_ptr rings, const float4* nodes, const float4* tris, const float4* mats, float4* ctx, ST& stack, unsigned long long* lc, unsigned long long* tdiag)
 {
@@ -212,47 +274,46 @@ HD void wf_trace_stage(const KParams& P, WfShared* Q, wf_ring_ptr rings, const f
     bool n_valid = false; // prefetched context
     uint32_t n_id = 0;
     float4 n0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), n1 = n0, n2 = n0;
+    uint32_t fin0 = 0u, fin1 = 0u; // finished contexts not handed over yet: (id + 1) | class << 16, 0 = none
+    // a lane's rays are done: hit record -> slot 7 of the context record (.x of the slot belongs to the SHADE stage), context noted for the hand-over
+    auto finish = [&]() {
+        uint32_t kk = WF_MISS, cls = 0u;
+        if (hit.prim != 0xffffffffu) {
+            kk = hit.k;
+            const float4* m = mats + f2bits(tris[hit.k * HJR_TRI_F4 + 2].z) * HJR_MAT_F4;
+            const float4 m0 = m[0], m3 = m[3];
+            cls = f2bits(m3.x) != 0 ? 0u : (f2bits(m3.y) != 0 ? 3u : (m0.w > 0.5f ? 2u : 1u)); // light | glass | metallic (msGGX) | Disney
+        }
+        float* hp = reinterpret_cast<float*>(ctx + (size_t)id * CTXF4 + 7) + 1;
+        hp[0] = hit.b1; hp[1] = hit.b2; hp[2] = bits2f(kk | (occluded ? 0x80000000u : 0u));
+        const uint32_t e = (id + 1u) | (cls << 16);
+        if (fin0 == 0u) fin0 = e; else fin1 = e;
+        phase = 2; cur = HJR_TRAV_DONE;
+    };
     for (;;) {
         if (WF_EXPIRED(4)) return;
-        const uint32_t n_wait = (uint32_t)__popcll(__ballot(phase >= 2));
-        if (n_wait >= P.wf_refill || n_wait == 64u) {
+        // ---- a lane without a ray starts its prefetched context (its loads were issued at least one hand-over ago)
+        if (phase == 2 && n_valid && fin1 == 0u) {
+            const uint32_t flags = f2bits(n1.w);
+            id = n_id;
+            ro = V(n0.x, n0.y, n0.z); db = V(n0.w, n1.x, n1.y); a_tmax = n1.z;
+            b_valid = flags & WF_TRACING; fresh = flags & WF_FRESH;
+            occluded = false;
+            hit.prim = 0xffffffffu; hit.t = 1e16f;
+            phase = (flags & WF_SH_VALID) ? 0 : 1; // a queued context has at least one of the two rays
+            o = (phase == 0 || !fresh) ? ro : cam_o;
+            d = (phase == 0) ? V(n2.x, n2.y, n2.z) : db;
+            R = box_ray(o, d);
+            sp = 0; cur = 0;
+            n_valid = false;
+        }
+        const uint32_t n_idle = (uint32_t)__popcll(__ballot(phase == 2));
+        const unsigned long long m_need = __ballot(!n_valid);
+        if (n_idle >= P.wf_refill || (uint32_t)__popcll(m_need) >= P.wf_prefetch_min) {
             const unsigned long long t_h0 = WF_NOW();
-            WF_T(6, 1); WF_T(7, __popcll(__ballot(phase == 3)));
-            // ---- hand the finished rays over: hit record -> slot 7 of the context record, context id -> the SHADE queue of what was hit
-            const bool fin = phase == 3;
-            if (__ballot(fin)) {
-                uint32_t cls = 0;
-                if (fin) {
-                    uint32_t kk = WF_MISS;
-                    if (hit.prim != 0xffffffffu) {
-                        kk = hit.k;
-                        const float4* m = mats + f2bits(tris[hit.k * HJR_TRI_F4 + 2].z) * HJR_MAT_F4;
-                        const float4 m0 = m[0], m3 = m[3];
-                        cls = f2bits(m3.x) != 0 ? 0u : (f2bits(m3.y) != 0 ? 3u : (m0.w > 0.5f ? 2u : 1u)); // light | glass | metallic (msGGX) | Disney
-                    }
-                    float* hp = reinterpret_cast<float*>(ctx + (size_t)id * CTXF4 + 7) + 1; // .x of the slot belongs to the SHADE stage
-                    hp[0] = hit.b1; hp[1] = hit.b2; hp[2] = bits2f(kk | (occluded ? 0x80000000u : 0u));
-                }
-                for (uint32_t q = 0; q < 4u; q++) wf_push(Q, rings, 1 + (int)q, fin && cls == q, id, cap);
-                if (fin) phase = 2;
-            }
-            // ---- empty lanes start their prefetched context (its loads were issued one hand-over ago)
-            if (phase == 2 && n_valid) {
-                const uint32_t flags = f2bits(n1.w);
-                id = n_id;
-                ro = V(n0.x, n0.y, n0.z); db = V(n0.w, n1.x, n1.y); a_tmax = n1.z;
-                b_valid = flags & WF_TRACING; fresh = flags & WF_FRESH;
-                occluded = false;
-                hit.prim = 0xffffffffu; hit.t = 1e16f;
-                phase = (flags & WF_SH_VALID) ? 0 : 1; // a queued context has at least one of the two rays
-                o = (phase == 0 || !fresh) ? ro : cam_o;
-                d = (phase == 0) ? V(n2.x, n2.y, n2.z) : db;
-                R = box_ray(o, d);
-                sp = 0; cur = 0;
-                n_valid = false;
-            }
-            // ---- and every lane without a prefetched context takes one from the TRACE queue
-            const unsigned long long m_need = __ballot(!n_valid);
+            WF_T(6, 1); WF_T(7, __popcll(__ballot(fin0 != 0u)) + __popcll(__ballot(fin1 != 0u)));
+            wf_push_shade(Q, rings, fin0, fin1, cap);
+            fin0 = fin1 = 0u;
             uint32_t start = 0;
             const uint32_t got = wf_pop(Q, 0, (uint32_t)__popcll(m_need), start);
             if (got) {
@@ -267,6 +328,7 @@ HD void wf_trace_stage(const KParams& P, WfShared* Q, wf_ring_ptr rings, const f
             WF_T(9, WF_NOW() - t_h0);
             if (__ballot(phase < 2 || n_valid) == 0ull) return;
         }
+        WF_T(15, 1); WF_T(16, __popcll(__ballot(phase < 2)));
         if (phase < 2) {
             if constexpr (SPECULATE) {
             // Speculative while-while (Aila & Laine; used by the layouts that read the BVH from memory: 291.5 -> 271.6 ms on the 1 M-triangle
@@ -314,10 +376,11 @@ HD void wf_trace_stage(const KParams& P, WfShared* Q, wf_ring_ptr rings, const f
             if (done) {
                 if (STATS) { if (phase == 0) lc[2] += 1; else lc[1] += 1; }
                 if (phase == 0 && b_valid) { phase = 1; o = fresh ? cam_o : ro; d = db; R = box_ray(o, d); sp = 0; cur = 0; }
-                else { phase = 3; cur = HJR_TRAV_DONE; }
+                else finish();
             }
             } else {
             while (!(cur & HJR_LEAF_FLAG)) { // every lane first descends through inner nodes until it holds a leaf (or is out of work) ...
+                WF_T(11, 1); WF_T(12, __popcll(__ballot(true)));
                 const float tfar = (phase == 0) ? a_tmax : hit.t;
                 const uint32_t nb = node_step<WIDTH, BLOCK, ST>(nodes, cur, R, tmin, tfar, stack, sp);
                 if (STATS) { if (phase == 0) lc[5] += nb; else lc[3] += nb; }
@@ -327,6 +390,7 @@ HD void wf_trace_stage(const KParams& P, WfShared* Q, wf_ring_ptr rings, const f
                 const uint32_t first = cur & 0x07ffffffu, count = (cur >> 27) & 15u;
                 const float tri_tmax = (phase == 0) ? a_tmax : 1e16f;
                 for (uint32_t i = 0; i < count; i++) {
+                    WF_T(13, 1); WF_T(14, __popcll(__ballot(true)));
                     const float4* g = tris + (first + i) * HJR_TRI_F4;
                     const float4 g0 = g[0], g1 = g[1], g2 = g[2];
                     float t, b1, b2;
@@ -352,7 +416,7 @@ HD void wf_trace_stage(const KParams& P, WfShared* Q, wf_ring_ptr rings, const f
                     o = fresh ? cam_o : ro; d = db;
                     R = box_ray(o, d);
                     sp = 0; cur = 0;
-                } else { phase = 3; cur = HJR_TRAV_DONE; }
+                } else finish();
             }
             }
         }
@@ -398,8 +462,8 @@ HD void wf_shade_stage(const KParams& P, WfShared* Q, wf_ring_ptr rings, int q, 
     const unsigned long long t_st = WF_NOW();
     WF_T(4, 1); WF_T(5, got);
     if (again || retry) wf_store_ctx<AOVS>(ctx, id, c, tracing);
-    wf_push(Q, rings, 0, again, id, cap);
-    wf_push(Q, rings, 1, retry, id, cap);
+    wf_push_trace(Q, rings, again, id, cap);
+    wf_push_shade(Q, rings, retry ? id + 1u : 0u, 0u, cap); // class 0
     const uint32_t retired = (uint32_t)__popcll(__ballot(have && !again && !retry)); // no ray and no item left: the context is finished
     if (retired && lane == 0u) atomicSub(&Q->live, retired);
     WF_T(10, WF_NOW() - t_st);
@@ -431,8 +495,12 @@ __global__ void __launch_bounds__(BLOCK, 1) hjr_wavefront_kernel(const KParams P
     const uint32_t cap = P.wf_cap;
     // all contexts start in SHADE queue 1 (class "path ends") with every flag clear: their first pass does nothing but take an item
     for (uint32_t i = threadIdx.x; i < HJR_WF_QUEUES * cap; i += BLOCK) rings[i] = (i >= cap && i < 2u * cap) ? (uint16_t)(i - cap + 1u) : (uint16_t)0;
-    if (threadIdx.x < HJR_WF_QUEUES) { Q->head[threadIdx.x] = 0u; Q->tail[threadIdx.x] = threadIdx.x == 1u ? cap : 0u; Q->commit[threadIdx.x] = threadIdx.x == 1u ? cap : 0u; }
-    if (threadIdx.x == 0u) { Q->live = cap; Q->items.range = 0ull; Q->items.lock = 0u; Q->items.exhausted = 0u; }
+    if (threadIdx.x < HJR_WF_QUEUES) Q->head[threadIdx.x] = 0u;
+    if (threadIdx.x == 0u) {
+        Q->tail0 = Q->commit0 = 0u;
+        Q->tail_s[0] = Q->commit_s[0] = (unsigned long long)cap; Q->tail_s[1] = Q->commit_s[1] = 0ull; // queue 1 holds every context
+        Q->live = cap; Q->items.range = 0ull; Q->items.lock = 0u; Q->items.exhausted = 0u;
+    }
 #ifdef HJR_WF_WATCHDOG
     if (threadIdx.x == 0u) wf_t0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -449,7 +517,7 @@ __global__ void __launch_bounds__(BLOCK, 1) hjr_wavefront_kernel(const KParams P
     if (STATS) for (int i = 0; i < HJR_NSTAT; i++) lc[i] = 0;
     WaveRange wr; wr.next = wr.end = 0u; wr.exhausted = false; wr.shared = &Q->items;
 #ifdef HJR_WF_TIMING
-    unsigned long long tdiag[11] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    unsigned long long tdiag[19] = { 0 };
 #else
     unsigned long long* tdiag = nullptr;
 #endif
@@ -460,7 +528,7 @@ __global__ void __launch_bounds__(BLOCK, 1) hjr_wavefront_kernel(const KParams P
         if (lane == 0u) {
             // published entries per queue (commit is read before head, so the difference can only err on the low side; clamp the rest)
             auto queued = [&](uint32_t q) {
-                const uint32_t cm = __hip_atomic_load(&Q->commit[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const uint32_t cm = wf_commit(Q, (int)q, __ATOMIC_RELAXED);
                 const uint32_t d = cm - __hip_atomic_load(&Q->head[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 return d > 0x7fffffffu ? 0u : d;
             };
@@ -480,7 +548,10 @@ __global__ void __launch_bounds__(BLOCK, 1) hjr_wavefront_kernel(const KParams P
 #ifdef HJR_WF_WATCHDOG
         if (pick != 6u && WF_EXPIRED(6)) { // diagnostic build: record the queue state of the first workgroup that runs out of time
             if (lane == 0u && atomicAdd(&P.stats[HJR_NSTAT], 1ull) == 0ull) {
-                for (int q = 0; q < HJR_WF_QUEUES; q++) { P.stats[HJR_NSTAT + 1 + q] = Q->commit[q]; P.stats[HJR_NSTAT + 6 + q] = Q->head[q]; P.stats[HJR_NSTAT + 11 + q] = Q->tail[q]; }
+                for (int q = 0; q < HJR_WF_QUEUES; q++) {
+                    P.stats[HJR_NSTAT + 1 + q] = wf_commit(Q, q, __ATOMIC_RELAXED); P.stats[HJR_NSTAT + 6 + q] = Q->head[q];
+                    P.stats[HJR_NSTAT + 11 + q] = q == 0 ? Q->tail0 : (uint32_t)(Q->tail_s[(q - 1) >> 1] >> (((q - 1) & 1) * 32));
+                }
                 P.stats[HJR_NSTAT + 16] = Q->live; P.stats[HJR_NSTAT + 17] = blockIdx.x; P.stats[HJR_NSTAT + 18] = (uint32_t)(Q->items.range >> 32) - (uint32_t)Q->items.range;
             }
             break;
@@ -501,7 +572,7 @@ __global__ void __launch_bounds__(BLOCK, 1) hjr_wavefront_kernel(const KParams P
         else { wf_shade_stage<INTEGRATOR, STATS, AOVS, WIDTH, BLOCK, ST>(P, Q, rings, (int)pick, nodes, tris, mats, lights, ctx, wr, stack, lc, tdiag); WF_T(2, WF_NOW() - t_g0); }
     }
 #ifdef HJR_WF_TIMING
-    if (lane == 0u) for (int i = 0; i < 11; i++) atomicAdd(&wf_diag[i], tdiag[i]);
+    if (lane == 0u) for (int i = 0; i < 19; i++) atomicAdd(&wf_diag[i], tdiag[i]);
 #endif
 
     if (STATS) {

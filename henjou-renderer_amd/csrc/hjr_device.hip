@@ -253,9 +253,11 @@ extern "C" int hjr_set_sky(hjr_ctx* c, const float* rgba, int w, int h)
 }
 
 template <int I, bool S, int W> static int launch_mem(hjr_ctx* c, const KParams& kp, uint64_t n_items, hipStream_t st);
-template <int I, bool S, int W, bool A> static int launch_mem2(hjr_ctx* c, const KParams& kp, uint64_t n_items, hipStream_t st);
+template <int I, bool S, int W, int A> static int launch_mem2(hjr_ctx* c, const KParams& kp, uint64_t n_items, hipStream_t st);
+// kernel variant of a launch (VAR of hjr_render_kernel / hjr_wavefront_kernel): 2 textures / sky texture, 1 albedo / normal AOVs, 0 colour only
+static int kernel_variant(const KParams& kp) { return (kp.tex_desc || kp.sky_tex) ? 2 : ((kp.aov_albedo || kp.aov_normal) ? 1 : 0); }
 // lds_mode: 0 = BVH4 read from memory, 1 = BVH2 staged in LDS with 32-bit stack entries, 2 = with 16-bit entries, 3 = BVH2 from memory
-template <int I, bool S, bool S16, bool A> static int launch_lds2(hjr_ctx* c, const KParams& kp, uint64_t n_items, hipStream_t st)
+template <int I, bool S, bool S16, int A> static int launch_lds2(hjr_ctx* c, const KParams& kp, uint64_t n_items, hipStream_t st)
 {
     const size_t smem = (((size_t)HJR_BLOCK_LDS * kp.stack_depth * (S16 ? 2 : 4) + 15) / 16) * 16 + ((size_t)kp.n_node_f4 + kp.n_tri_f4 + kp.n_mat_f4 + kp.n_light_f4) * 16;
     auto kern = hjr_render_kernel<I, S, HJR_BLOCK_LDS, true, S16, 2, A>;
@@ -269,13 +271,13 @@ template <int I, bool S, bool S16, bool A> static int launch_lds2(hjr_ctx* c, co
 // the albedo / normal AOV sums cost 6 VGPRs per lane: a separate instantiation for callers that only want aov_color
 template <int I, bool S, bool S16> static int launch_lds(hjr_ctx* c, const KParams& kp, uint64_t n_items, hipStream_t st)
 {
-    const bool full = kp.aov_albedo || kp.aov_normal || kp.tex_desc || kp.sky_tex;
-    return full ? launch_lds2<I, S, S16, true>(c, kp, n_items, st) : launch_lds2<I, S, S16, false>(c, kp, n_items, st);
+    const int var = kernel_variant(kp);
+    return var == 2 ? launch_lds2<I, S, S16, 2>(c, kp, n_items, st) : (var == 1 ? launch_lds2<I, S, S16, 1>(c, kp, n_items, st) : launch_lds2<I, S, S16, 0>(c, kp, n_items, st));
 }
 // Workgroup-local wavefront kernel (hjr_wavefront.hip.h): one 1024-thread workgroup per CU for every layout.  LDS holds the top of
 // the traversal stacks, the scene tables (LDS layouts), the queue header, the hit slots and the id rings; what is left after the
 // fixed parts decides how many stack entries per lane stay in LDS (the rest overflows to HBM).  Returns -2 when the layout does not fit.
-template <int I, bool S, bool LDS, bool SP, int W, bool A> static int launch_wf3(hjr_ctx* c, const KParams& kp, uint64_t n_items, uint32_t cap, uint32_t lds_entries, size_t smem, hipStream_t st)
+template <int I, bool S, bool LDS, bool SP, int W, int A> static int launch_wf3(hjr_ctx* c, const KParams& kp, uint64_t n_items, uint32_t cap, uint32_t lds_entries, size_t smem, hipStream_t st)
 {
     auto kern = hjr_wavefront_kernel<I, S, HJR_BLOCK_LDS, LDS, SP, W, A>;
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return -1;
@@ -288,13 +290,14 @@ template <int I, bool S, bool LDS, bool SP, int W, bool A> static int launch_wf3
     if (const char* e = getenv("HJR_WF_REFILL")) { int v = atoi(e); if (v >= 1 && v <= 64) k2.wf_refill = (uint32_t)v; }       // tuning knobs
     if (const char* e = getenv("HJR_WF_PREFETCH_MIN")) { int v = atoi(e); if (v >= 1 && v <= 64) k2.wf_prefetch_min = (uint32_t)v; }
     if (const char* e = getenv("HJR_WF_TRACE_MIN")) { int v = atoi(e); if (v >= 1 && v <= 4096) k2.wf_trace_min = (uint32_t)v; }
-    const size_t ctx_bytes = (size_t)(A ? HJR_WF_CTX_F4_FULL : HJR_WF_CTX_F4_LEAN) * 16 * blocks * cap;
+    const size_t ctx_bytes = (size_t)(HJR_WF_CTX_F4 + (A ? HJR_WF_AOV_F4 : 0)) * 16 * blocks * cap; // context records, then (albedo / normal launches) the AOV sums
     if (c->d_wf_ctx.cap < ctx_bytes) {
         c->d_wf_ctx.release();
         if (hipMalloc(&c->d_wf_ctx.p, ctx_bytes) != hipSuccess) return -1;
         c->d_wf_ctx.cap = ctx_bytes;
     }
     k2.wf_ctx = (float4*)c->d_wf_ctx.p;
+    k2.wf_aov = A ? k2.wf_ctx + (size_t)HJR_WF_CTX_F4 * blocks * cap : nullptr;
     k2.stack_lds_entries = lds_entries;
     k2.spill_stride = (uint32_t)(blocks * HJR_BLOCK_LDS);
     const uint32_t over = kp.stack_depth > lds_entries ? kp.stack_depth - lds_entries : 0u;
@@ -311,7 +314,7 @@ template <int I, bool S, bool LDS, bool SP, int W, bool A> static int launch_wf3
 }
 // LDS holds the (top of the) traversal stacks, the scene tables (LDS layouts), the queue header and the id rings; what is left after the
 // fixed parts decides how many stack entries per lane stay in LDS.  Returns -2 when the layout does not fit.
-template <int I, bool S, bool LDS, int W, bool A> static int launch_wf2(hjr_ctx* c, const KParams& kp, uint64_t n_items, hipStream_t st)
+template <int I, bool S, bool LDS, int W, int A> static int launch_wf2(hjr_ctx* c, const KParams& kp, uint64_t n_items, hipStream_t st)
 {
     uint32_t cap = LDS ? 2048 : 4096; // contexts per workgroup: more of them in flight pay when every node comes from memory (1 M triangles: 272 -> 259 ms)
     if (const char* e = getenv("HJR_WF_CAP")) { int v = atoi(e); if (v >= 64 && v <= 32768 && (v & (v - 1)) == 0) cap = (uint32_t)v; }
@@ -331,8 +334,8 @@ template <int I, bool S, bool LDS, int W, bool A> static int launch_wf2(hjr_ctx*
 }
 template <int I, bool S, bool LDS, int W> static int launch_wf1(hjr_ctx* c, const KParams& kp, uint64_t n_items, hipStream_t st)
 {
-    const bool full = kp.aov_albedo || kp.aov_normal || kp.tex_desc || kp.sky_tex;
-    return full ? launch_wf2<I, S, LDS, W, true>(c, kp, n_items, st) : launch_wf2<I, S, LDS, W, false>(c, kp, n_items, st);
+    const int var = kernel_variant(kp);
+    return var == 2 ? launch_wf2<I, S, LDS, W, 2>(c, kp, n_items, st) : (var == 1 ? launch_wf2<I, S, LDS, W, 1>(c, kp, n_items, st) : launch_wf2<I, S, LDS, W, 0>(c, kp, n_items, st));
 }
 template <int I, bool S> static int launch_wf(hjr_ctx* c, const KParams& kp, uint64_t n_items, int lds_mode, hipStream_t st)
 {
@@ -340,28 +343,41 @@ template <int I, bool S> static int launch_wf(hjr_ctx* c, const KParams& kp, uin
     if (lds_mode == 3) return launch_wf1<I, S, false, 2>(c, kp, n_items, st);
     return launch_wf1<I, S, false, 4>(c, kp, n_items, st);
 }
-template <int I, bool S> static int launch(hjr_ctx* c, const KParams& kp, uint64_t n_items, int lds_mode, hipStream_t st)
+// descent loops of the fused traversals (hjr_traverse.hip.h): lanes still descending below which a pass moves on to the leaves
+#ifndef HJR_NODE_MIN_LDS
+#define HJR_NODE_MIN_LDS 4     /* megakernel, LDS-resident scenes (with AOVs, 1 / 4 / 8 / 12 / 16: 139.8 / 128.9 / 129.8 / 135.2 / 140.4 ms) */
+#endif
+#ifndef HJR_NODE_MIN_LDS_WF
+#define HJR_NODE_MIN_LDS_WF 8  /* wavefront kernel, LDS-resident scenes (1 / 4 / 8 / 12 / 16: 132.4 / 125.4 / 124.8 / 125.7 / 126.4 ms) */
+#endif
+#ifndef HJR_NODE_MIN_MEM
+#define HJR_NODE_MIN_MEM 24    /* scenes read from memory (1 M triangles, 1 / 8 / 16 / 24 / 32: megakernel 280 / 197 / 180 / 179 / 190 ms, wavefront 255 / 213 / 194 / 189 / 192) */
+#endif
+template <int I, bool S> static int launch(hjr_ctx* c, const KParams& kp_in, uint64_t n_items, int lds_mode, hipStream_t st)
 {
+    KParams kp = kp_in;
+    const char* nm_env = getenv("HJR_NODE_MIN"); // tuning knob
+    const uint32_t nm_forced = nm_env && atoi(nm_env) >= 1 && atoi(nm_env) <= 64 ? (uint32_t)atoi(nm_env) : 0u;
     // Two kernel families produce the same bits (hjr_kernel.hip.h / hjr_wavefront.hip.h); which one is faster depends on the launch
-    // (MI355X, profiles/r02_experiments.md).  Bundled scene (LDS-resident), 1080p x 256 spp: MIS 197 ms wavefront vs 238 ms megakernel (its
-    // two extra rays per bounce are traced by sorted, full waves), NEE colour-only 131.6 vs 135.1, NEE with albedo / normal AOVs 147.6 vs
-    // 137.1 (the context record grows past one cache line), Pathtrace 104.4 vs 99.2.  Scenes read from memory (1 M triangles, 1080p x 64
-    // spp): MIS 519 vs 729 ms, NEE 259 vs 276 (250 k triangles: 144 vs 147).  HJR_PIPELINE=mega | wf overrides the choice.
+    // (MI355X, profiles/r02_experiments.md §4).  Bundled scene (LDS-resident), 1080p x 256 spp: MIS 193 ms wavefront vs 234 ms megakernel
+    // (the NEE shadow ray and the next closest-hit ray of its bounce are traced by sorted, full waves), NEE colour-only 126.7 vs 126.6,
+    // NEE with albedo / normal AOVs 145.7 vs 128.9, Pathtrace 104.7 vs 91.2.  Scenes read from memory (1 M triangles, 1080p x 64 spp):
+    // MIS 416 vs 635 ms, NEE 188 vs 179.  So: MIS -> wavefront kernel, everything else -> megakernel.  HJR_PIPELINE=mega | wf overrides.
     const char* pe = getenv("HJR_PIPELINE");
-    const bool full_variant = kp.aov_albedo || kp.aov_normal || kp.tex_desc || kp.sky_tex;
     const bool lds_layout = lds_mode == 1 || lds_mode == 2;
-    const bool big_scene = !lds_layout && c->frame.n_tris >= 200000u; // NEE, 1 M triangles: 259 (wavefront, 4096 contexts) vs 276 ms; 250 k: 144 vs 147
-    bool wf = I == HJR_INTEGRATOR_MIS || (I == HJR_INTEGRATOR_NEE && ((lds_layout && !full_variant) || big_scene));
+    bool wf = I == HJR_INTEGRATOR_MIS;
     if (pe && strcmp(pe, "wf") == 0) wf = true;
     if (pe && strcmp(pe, "mega") == 0) wf = false;
     // the wavefront kernel's queue positions are free-running 32-bit counters per workgroup (hjr_wavefront.hip.h::WfShared): a context is
     // queued at most ~12 times per sample; frames that could bring one workgroup near 2^32 pushes (4x its even share) stay with the megakernel
     if ((double)n_items * kp.chunk_spp * 12.0 * 4.0 / (double)(c->n_cus > 0 ? c->n_cus : 1) >= 4.0e9) wf = false;
     c->stats.pipeline = wf ? 1u : 0u;
+    kp.node_min = nm_forced ? nm_forced : (lds_layout ? (wf ? HJR_NODE_MIN_LDS_WF : HJR_NODE_MIN_LDS) : HJR_NODE_MIN_MEM);
     if (wf) {
         const int rc = launch_wf<I, S>(c, kp, n_items, lds_mode, st);
         if (rc != -2) return rc;
         c->stats.pipeline = 0u; // the scene tables + queues do not fit LDS in this layout: megakernel
+        if (!nm_forced) kp.node_min = lds_layout ? HJR_NODE_MIN_LDS : HJR_NODE_MIN_MEM;
     }
     if (lds_mode == 1) return launch_lds<I, S, false>(c, kp, n_items, st);
     if (lds_mode == 2) return launch_lds<I, S, true>(c, kp, n_items, st);
@@ -370,10 +386,10 @@ template <int I, bool S> static int launch(hjr_ctx* c, const KParams& kp, uint64
 }
 template <int I, bool S, int W> static int launch_mem(hjr_ctx* c, const KParams& kp, uint64_t n_items, hipStream_t st)
 {
-    const bool full = kp.aov_albedo || kp.aov_normal || kp.tex_desc || kp.sky_tex;
-    return full ? launch_mem2<I, S, W, true>(c, kp, n_items, st) : launch_mem2<I, S, W, false>(c, kp, n_items, st);
+    const int var = kernel_variant(kp);
+    return var == 2 ? launch_mem2<I, S, W, 2>(c, kp, n_items, st) : (var == 1 ? launch_mem2<I, S, W, 1>(c, kp, n_items, st) : launch_mem2<I, S, W, 0>(c, kp, n_items, st));
 }
-template <int I, bool S, int W, bool A> static int launch_mem2(hjr_ctx* c, const KParams& kp, uint64_t n_items, hipStream_t st)
+template <int I, bool S, int W, int A> static int launch_mem2(hjr_ctx* c, const KParams& kp, uint64_t n_items, hipStream_t st)
 {
     uint32_t short_stack = HJR_SHORT_STACK;
     if (const char* e = getenv("HJR_SHORT_STACK")) { int v = atoi(e); if (v >= 1 && v <= 64) short_stack = (uint32_t)v; } // tests force the overflow path with 2

@@ -205,6 +205,7 @@ struct LaneCtx {
     uint32_t s;         // current sample of the item's run
     uint32_t it_cost;   // closest-hit rays traced for the current item (feeds the measured-cost tile order)
     f3 sumL, sumA, sumN;
+    float4* aov;        // wavefront kernel, albedo / normal launches: the item's (sumA, sumN) live in memory here instead of in sumA / sumN (nullptr: in registers)
     f3 sh_d, sh_contrib; // pending shadow ray: direction and the contribution that is added iff it is unoccluded
     f3 mis_contrib;      // MIS only: the BSDF-sampled light term of the bounce shaded last, added right after the pending NEE term is resolved
     float sh_tmax;
@@ -218,6 +219,7 @@ HD void ctx_reset(LaneCtx& c)
     c.has_item = c.dead = c.path_live = c.fin_pending = c.write_pending = c.sh_valid = false;
     c.fresh = true;
     c.item = c.s = c.it_cost = 0u;
+    c.aov = nullptr;
     c.sumL = c.sumA = c.sumN = c.sh_d = c.sh_contrib = c.mis_contrib = V1(0.0f);
     c.sh_tmax = 0.0f;
     c.ps.ro = c.ps.rd = c.ps.thr = c.ps.L = V1(0.0f);
@@ -295,17 +297,19 @@ template <bool AOVS> HD void write_out(const KParams& P, LaneCtx& c)
     // AOV element of the pixel: row-major frame, or (HJR_FLAG_PACKED) this rank's tiles back to back: (owned tile index) * 64 + pixel in tile
     const size_t pix = P.packed ? (size_t)(((HJR_PY(c) / HJR_TILE) * P.tiles_x + HJR_PX(c) / HJR_TILE) / P.world) * 64u + ((HJR_PY(c) & 7u) * 8u + (HJR_PX(c) & 7u))
                                 : (size_t)HJR_PX(c) + (size_t)HJR_PY(c) * P.width;
+    f3 sumA = c.sumA, sumN = c.sumN;
+    if (AOVS && c.aov) { const float4 a = c.aov[0], n = c.aov[1]; sumA = V(a.x, a.y, a.z); sumN = V(n.x, n.y, n.z); }
     if (P.n_chunks == 1u) { // the item is the whole pixel: mean = chunk sum * (1 / spp)
         P.aov_color[pix] = make_float4(c.sumL.x * inv_spp, c.sumL.y * inv_spp, c.sumL.z * inv_spp, 1.0f);
-        if (AOVS && P.aov_albedo) P.aov_albedo[pix] = make_float4(c.sumA.x * inv_spp, c.sumA.y * inv_spp, c.sumA.z * inv_spp, 1.0f);
-        if (AOVS && P.aov_normal) P.aov_normal[pix] = make_float4(c.sumN.x * inv_spp, c.sumN.y * inv_spp, c.sumN.z * inv_spp, 1.0f);
+        if (AOVS && P.aov_albedo) P.aov_albedo[pix] = make_float4(sumA.x * inv_spp, sumA.y * inv_spp, sumA.z * inv_spp, 1.0f);
+        if (AOVS && P.aov_normal) P.aov_normal[pix] = make_float4(sumN.x * inv_spp, sumN.y * inv_spp, sumN.z * inv_spp, 1.0f);
     } else { // chunk sum -> HBM; hjr_finalize_kernel adds the chunks of a pixel in chunk order.  The buffers hold this rank's
              // tiles only: slot = ((chunk * owned tiles) + owned tile index) * 64 + pixel in tile
         const uint32_t otile = ((HJR_PY(c) / HJR_TILE) * P.tiles_x + HJR_PX(c) / HJR_TILE) / P.world;
         const size_t slot = ((size_t)HJR_CHUNK(c) * P.n_owned_tiles + otile) * 64u + ((HJR_PY(c) & 7u) * 8u + (HJR_PX(c) & 7u));
         P.part_color[slot] = make_float4(c.sumL.x, c.sumL.y, c.sumL.z, 0.0f);
-        if (AOVS && P.part_albedo) P.part_albedo[slot] = make_float4(c.sumA.x, c.sumA.y, c.sumA.z, 0.0f);
-        if (AOVS && P.part_normal) P.part_normal[slot] = make_float4(c.sumN.x, c.sumN.y, c.sumN.z, 0.0f);
+        if (AOVS && P.part_albedo) P.part_albedo[slot] = make_float4(sumA.x, sumA.y, sumA.z, 0.0f);
+        if (AOVS && P.part_normal) P.part_normal[slot] = make_float4(sumN.x, sumN.y, sumN.z, 0.0f);
     }
     c.write_pending = false;
 }
@@ -406,7 +410,9 @@ HD void bounce_pre_trace(const KParams& P, LaneCtx& c, WaveRange& wr, const bool
                         c.has_item = true; c.path_live = false;
                         c.item = px | (py << 13) | (chunk << 26);
                         c.s = chunk * P.chunk_spp;
-                        c.sumL = V1(0.0f); c.sumA = V1(0.0f); c.sumN = V1(0.0f);
+                        c.sumL = V1(0.0f);
+                        if (AOVS && c.aov) c.aov[0] = c.aov[1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                        else { c.sumA = V1(0.0f); c.sumN = V1(0.0f); }
                     }
                 } else c.dead = true;
             }
@@ -428,7 +434,7 @@ HD void bounce_pre_trace(const KParams& P, LaneCtx& c, WaveRange& wr, const bool
 
 // ---- second half of a bounce, for a lane whose rays of this round are resolved: `occluded` answers the pending shadow ray
 // (if c.sh_valid), `h` the closest-hit ray (if tracing).  Lane-private: no cross-lane operation inside.
-template <int INTEGRATOR, bool STATS, bool AOVS, int WIDTH, int BLOCK, typename ST>
+template <int INTEGRATOR, bool STATS, bool AOVS, bool TEX, int WIDTH, int BLOCK, typename ST>
 HD void bounce_post_trace(const KParams& P, const float4* nodes, const float4* tris, const float4* mats, const float4* lights, LaneCtx& c,
                           const bool tracing, const bool occluded, const Hit& h, ST& stack, unsigned long long* lc)
 {
@@ -447,9 +453,16 @@ HD void bounce_post_trace(const KParams& P, const float4* nodes, const float4* t
     if (!tracing) return;
 
     c.it_cost++;
+    float4 aov0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), aov1 = aov0;
+    if (AOVS && c.aov && ps.depth == 0) { aov0 = c.aov[0]; aov1 = c.aov[1]; } // sums in memory: the loads fly while the hit program runs
     HitInfo prd;
-    hit_program<STATS, AOVS>(P, tris, mats, h, ps.rd, prd, lc);
-    if (AOVS && ps.depth == 0) { c.sumA = c.sumA + prd.surf.basecolor; c.sumN = c.sumN + prd.normal; } // rt.h:191-194
+    hit_program<STATS, TEX>(P, tris, mats, h, ps.rd, prd, lc);
+    if (AOVS && ps.depth == 0) { // rt.h:191-194
+        if (c.aov) {
+            c.aov[0] = make_float4(aov0.x + prd.surf.basecolor.x, aov0.y + prd.surf.basecolor.y, aov0.z + prd.surf.basecolor.z, 0.0f);
+            c.aov[1] = make_float4(aov1.x + prd.normal.x, aov1.y + prd.normal.y, aov1.z + prd.normal.z, 0.0f);
+        } else { c.sumA = c.sumA + prd.surf.basecolor; c.sumN = c.sumN + prd.normal; }
+    }
     if (!prd.is_hit || prd.is_light) {
         // NEE / MIS count emission only at depth 0 (rt.h:196-208, 318-330); Pathtrace always (rt.h:118-126)
         if (INTEGRATOR == HJR_INTEGRATOR_PT_ || ps.depth == 0) ps.L = ps.L + ps.thr * prd.emission;
@@ -512,7 +525,7 @@ HD void bounce_post_trace(const KParams& P, const float4* nodes, const float4* t
         const f3 wi = local_to_world(local_wi, t, n, b);
         const float cosine1 = absdot(wi, n);
         HitInfo lh;
-        ray_trace<STATS, AOVS, WIDTH, BLOCK, ST>(P, nodes, tris, mats, prd.position, wi, lh, stack, lc);
+        ray_trace<STATS, TEX, WIDTH, BLOCK, ST>(P, nodes, tris, mats, prd.position, wi, lh, stack, lc);
         bool have_term = false;
         f3 term = V1(0.0f);
         if (lh.is_hit) {
@@ -591,11 +604,13 @@ HD void stage_scene_in_lds(const KParams& P, float4* base, const float4*& nodes,
 }
 
 // ------------------------------------------------------------------ the megakernel
-// AOVS = the "full" variant: albedo / normal AOV sums, material textures and the equirect sky texture; the lean variant
-// (colour only, untextured scene, constant sky) saves registers
-template <int INTEGRATOR, bool STATS, int BLOCK, bool LDSBVH, bool STACK16, int WIDTH, bool AOVS>
+// VAR: 0 = lean (colour only, untextured scene, constant sky), 1 = + albedo / normal AOV sums, 2 = + material textures, normal maps
+// and the equirect sky texture.  Each step costs registers (NEE, LDS layout: 20 / 25 / 48 VGPR spills), so a launch gets the
+// smallest variant that does what it needs.
+template <int INTEGRATOR, bool STATS, int BLOCK, bool LDSBVH, bool STACK16, int WIDTH, int VAR>
 __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_render_kernel(const KParams P)
 {
+    constexpr bool AOVS = VAR >= 1, TEX = VAR == 2;
     typedef typename std::conditional<STACK16, uint16_t, uint32_t>::type SE; // stack entry type
     typedef LaneStack<SE, BLOCK, !LDSBVH, STATS> ST;
     ST stack;
@@ -641,7 +656,7 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
         {
             Counters ca, cb; ca.box = ca.tri = cb.box = cb.tri = 0;
             const f3 cam_o = V(P.cam_pos[0], P.cam_pos[1], P.cam_pos[2]);
-            inflight = traverse_fused<STATS, WIDTH, BLOCK, ST, (LDSBVH ? HJR_CARRY_LDS : HJR_CARRY_MEM)>(nodes, tris, c.sh_valid, c.ps.ro, c.sh_d, c.sh_tmax, tracing, c.fresh ? cam_o : c.ps.ro, c.ps.rd, occluded, h, stack, ca, cb, inflight, tc);
+            inflight = traverse_fused<STATS, WIDTH, BLOCK, ST, (LDSBVH ? HJR_CARRY_LDS : HJR_CARRY_MEM)>(nodes, tris, c.sh_valid, c.ps.ro, c.sh_d, c.sh_tmax, tracing, c.fresh ? cam_o : c.ps.ro, c.ps.rd, occluded, h, stack, ca, cb, inflight, tc, P.node_min);
             if (STATS) { // tests are counted round by round, rays when they are resolved
                 lc[5] += ca.box; lc[6] += ca.tri; lc[3] += cb.box; lc[4] += cb.tri;
                 if (!inflight) { if (c.sh_valid) lc[2] += 1; if (tracing) lc[1] += 1; }
@@ -651,7 +666,7 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
 #ifdef HJR_TIMING
         oc[3] += __popcll(__ballot(!inflight && (tracing || c.sh_valid)));
 #endif
-        if (!inflight) bounce_post_trace<INTEGRATOR, STATS, AOVS, WIDTH, BLOCK, ST>(P, nodes, tris, mats, lights, c, tracing, occluded, h, stack, lc);
+        if (!inflight) bounce_post_trace<INTEGRATOR, STATS, AOVS, TEX, WIDTH, BLOCK, ST>(P, nodes, tris, mats, lights, c, tracing, occluded, h, stack, lc);
         HJR_TICK(2)
     }
 #ifdef HJR_TIMING

@@ -46,7 +46,9 @@ struct KParams {
     uint32_t cost_div;               // 64 * spp: rays per tile at one ray per sample
     uint32_t spill_stride;           // lanes in the grid
     uint32_t stack_lds_entries;      // memory-path kernels: stack entries per lane kept in LDS (the rest overflow to stack_spill)
-    float4* wf_ctx;                  // wavefront kernel: context records, [workgroup][wf_cap] x 128 (192) bytes (hjr_wavefront.hip.h)
+    uint32_t node_min;               // descent loop of the fused traversals: lanes still holding an inner node below which a pass moves on to the leaves (hjr_traverse.hip.h)
+    float4* wf_ctx;                  // wavefront kernel: context records, [workgroup][wf_cap] x 128 bytes (hjr_wavefront.hip.h)
+    float4* wf_aov;                  // wavefront kernel, albedo / normal launches: per-context AOV sums, [workgroup][wf_cap] x 32 bytes
     uint32_t wf_cap;                 // contexts per workgroup (power of two, <= 32768: ids travel as uint16 + 1)
     uint32_t wf_refill, wf_trace_min; // trace-stage hand-over threshold (lanes without a ray) / scheduler preference for TRACE (queued rays)
     uint32_t wf_prefetch_min;        // trace-stage hand-over threshold (lanes that have used up their prefetched context)

@@ -224,6 +224,13 @@ HD bool traverse(const float4* nodes, const float4* tris, f3 o, f3 d, float tmin
 // max(tripsA) + max(tripsB) — the SIMT cost of per-lane trip-count variance drops by ~1/3 (profiles/r01_experiments.md).
 // Results are identical to two separate traversals.
 //
+// Lane threshold of the descent loop (node_min; also in hjr_wavefront.hip.h::wf_trace_stage): the lanes descend together until every
+// lane holds a leaf — or until fewer than node_min lanes are still descending.  Those few keep their inner node and carry on in the
+// next pass of the outer loop, next to the lanes that have meanwhile finished their leaf, instead of holding the whole wave idle for
+// their descent (1 M triangles: 28 descent iterations per pass with 18 of 64 lanes working before; 277 -> 179 ms with node_min = 24;
+// bundled scene 134 -> 129 ms with 4).  Which triangles a lane tests, and in which order, does not change.  (The stand-alone
+// traverse() above keeps the plain loop: with the threshold MIS ran 3 % slower on the bundled scene.)
+//
 // Straggler carry-over (CARRY > 0): the loop also ends when at most CARRY lanes are still traversing (and at least one
 // lane of this round has finished).  Those lanes keep their traversal state (TravCarry + hit + their LDS stack column),
 // skip the shading that follows and resume in the next round next to the other lanes' new rays: the wave's trip count per
@@ -239,7 +246,7 @@ HD bool traverse(const float4* nodes, const float4* tris, f3 o, f3 d, float tmin
 struct TravCarry { uint32_t cur; int sp, phase; };
 template <bool STATS, int WIDTH, int BLOCK, typename ST, int CARRY>
 HD bool traverse_fused(const float4* nodes, const float4* tris, const bool a_valid, const f3 ao, const f3 ad, const float a_tmax, const bool b_valid,
-                       const f3 bo, const f3 bd, bool& occluded, Hit& hit, ST& stack, Counters& ca, Counters& cb, const bool resume, TravCarry& tc)
+                       const f3 bo, const f3 bd, bool& occluded, Hit& hit, ST& stack, Counters& ca, Counters& cb, const bool resume, TravCarry& tc, const uint32_t node_min)
 {
     const float tmin = 0.001f;
     int phase, sp;
@@ -263,15 +270,20 @@ HD bool traverse_fused(const float4* nodes, const float4* tris, const bool a_val
             if (n_act == 0 || (n_act <= CARRY && n_act < n_start)) break;
         } else if (__ballot(phase < 2) == 0ull) break;
         if (phase < 2) {
-        // "while-while" traversal: every lane first descends through inner nodes until it holds a leaf (or is out of work) ...
-        while (!(cur & HJR_LEAF_FLAG)) {
-            const float tfar = (phase == 0) ? a_tmax : hit.t;
-            const uint32_t nb = node_step<WIDTH, BLOCK, ST>(nodes, cur, R, tmin, tfar, stack, sp);
-            if (STATS) { if (phase == 0) ca.box += nb; else cb.box += nb; }
+        // "while-while" traversal: every lane first descends through inner nodes until it holds a leaf (or is out of work), or until
+        // fewer than node_min lanes are still descending (they go on in the next pass) ...
+        for (;;) {
+            if (!(cur & HJR_LEAF_FLAG)) {
+                const float tfar = (phase == 0) ? a_tmax : hit.t;
+                const uint32_t nb = node_step<WIDTH, BLOCK, ST>(nodes, cur, R, tmin, tfar, stack, sp);
+                if (STATS) { if (phase == 0) ca.box += nb; else cb.box += nb; }
+            }
+            const uint32_t n_inner = (uint32_t)__popcll(__ballot(!(cur & HJR_LEAF_FLAG)));
+            if (n_inner == 0u || n_inner < node_min) break;
         }
-        // ... then all lanes test their leaf's triangles together
+        // ... then all lanes that hold a leaf test its triangles together
         bool done = (cur == HJR_TRAV_DONE);
-        if (!done) {
+        if (!done && (cur & HJR_LEAF_FLAG)) {
             const uint32_t first = cur & 0x07ffffffu, count = (cur >> 27) & 15u;
             const float tri_tmax = (phase == 0) ? a_tmax : 1e16f;
             for (uint32_t i = 0; i < count; i++) {

@@ -199,19 +199,22 @@ HD void wf_push_shade(WfShared* Q, wf_ring_ptr rings, uint32_t e0, uint32_t e1, 
     }
 }
 
-// ---- context records: one per context id, HJR_WF_CTX_F4_LEAN float4 = 128 bytes = exactly one cache line (the albedo / normal
-// variant appends two float4 and pads to 192 bytes).  A stage loads / stores a context with consecutive dwordx4 accesses of ONE
-// line per lane; plane-major arrays (one line per 16-byte access) cost 8x the L2 traffic and ran 1.7x slower.
+// ---- context records: one per context id, HJR_WF_CTX_F4 float4 = 128 bytes = exactly one cache line.  A stage loads / stores a
+// context with consecutive dwordx4 accesses of ONE line per lane; plane-major arrays (one line per 16-byte access) cost 8x the L2
+// traffic and ran 1.7x slower.
 //   0: ro.xyz rd.x   1: rd.yz sh_tmax flags   2: sh_d.xyz item   3: thr.xyz s   4: L.xyz mis.x   5: sumL.xyz (depth | rng_depth << 8 | it_cost << 20)
-//   6: sh_contrib.xyz mis.y   7: mis.z | hit b1 b2 (k | occluded << 31)   8: sumA.xyz -   9: sumN.xyz -      (8, 9: AOVS variant only)
+//   6: sh_contrib.xyz mis.y   7: mis.z | hit b1 b2 (k | occluded << 31)
 // (mis = LaneCtx::mis_contrib; slot 7 .yzw is written by the TRACE stage, everything else by the SHADE stage)
-#define HJR_WF_CTX_F4_LEAN 8
-#define HJR_WF_CTX_F4_FULL 12
-template <bool AOVS> HD void wf_store_ctx(float4* ctx, uint32_t id, const LaneCtx& c, bool tracing)
+// The albedo / normal sums of a launch with those AOVs live in a second array (HJR_WF_AOV_F4 float4 per context: sumA, sumN): they
+// change once per SAMPLE (first hit: a read-modify-write there, LaneCtx::aov), the record is read and written once per BOUNCE by two
+// stages — carrying them in the record (192 bytes, records straddling cache lines) cost 16 ms of 131 on the bundled scene.
+#define HJR_WF_CTX_F4 8
+#define HJR_WF_AOV_F4 2
+HD void wf_store_ctx(float4* ctx, uint32_t id, const LaneCtx& c, bool tracing)
 {
     const uint32_t flags = (c.has_item ? WF_HAS_ITEM : 0u) | (c.dead ? WF_DEAD : 0u) | (c.path_live ? WF_PATH_LIVE : 0u) | (c.fin_pending ? WF_FIN_PENDING : 0u) |
                            (c.write_pending ? WF_WRITE_PENDING : 0u) | (c.sh_valid ? WF_SH_VALID : 0u) | (c.fresh ? WF_FRESH : 0u) | (tracing ? WF_TRACING : 0u);
-    float4* p = ctx + (size_t)id * (AOVS ? HJR_WF_CTX_F4_FULL : HJR_WF_CTX_F4_LEAN);
+    float4* p = ctx + (size_t)id * HJR_WF_CTX_F4;
     p[0] = make_float4(c.ps.ro.x, c.ps.ro.y, c.ps.ro.z, c.ps.rd.x);
     p[1] = make_float4(c.ps.rd.y, c.ps.rd.z, c.sh_tmax, bits2f(flags));
     p[2] = make_float4(c.sh_d.x, c.sh_d.y, c.sh_d.z, bits2f(c.item));
@@ -221,14 +224,10 @@ template <bool AOVS> HD void wf_store_ctx(float4* ctx, uint32_t id, const LaneCt
     p[5] = make_float4(c.sumL.x, c.sumL.y, c.sumL.z, bits2f(((uint32_t)c.ps.depth & 0xffu) | ((c.ps.rng_depth & 0xfffu) << 8) | ((c.it_cost & 0xfffu) << 20)));
     p[6] = make_float4(c.sh_contrib.x, c.sh_contrib.y, c.sh_contrib.z, c.mis_contrib.y);
     reinterpret_cast<float*>(p + 7)[0] = c.mis_contrib.z;
-    if (AOVS) {
-        p[8] = make_float4(c.sumA.x, c.sumA.y, c.sumA.z, 0.0f);
-        p[9] = make_float4(c.sumN.x, c.sumN.y, c.sumN.z, 0.0f);
-    }
 }
-template <bool AOVS> HD void wf_load_ctx(const float4* ctx, uint32_t id, LaneCtx& c, bool& tracing, float4& hitrec)
+HD void wf_load_ctx(const float4* ctx, uint32_t id, LaneCtx& c, bool& tracing, float4& hitrec)
 {
-    const float4* p = ctx + (size_t)id * (AOVS ? HJR_WF_CTX_F4_FULL : HJR_WF_CTX_F4_LEAN);
+    const float4* p = ctx + (size_t)id * HJR_WF_CTX_F4;
     const float4 a = p[0], b = p[1], d = p[2], e = p[3], f = p[4], g = p[5], h = p[6];
     hitrec = p[7];
     const uint32_t flags = f2bits(b.w);
@@ -241,10 +240,7 @@ template <bool AOVS> HD void wf_load_ctx(const float4* ctx, uint32_t id, LaneCtx
     c.ps.L = V(f.x, f.y, f.z);
     c.sumL = V(g.x, g.y, g.z); c.ps.depth = (int)(f2bits(g.w) & 0xffu); c.ps.rng_depth = (f2bits(g.w) >> 8) & 0xfffu; c.it_cost = f2bits(g.w) >> 20;
     c.sh_contrib = V(h.x, h.y, h.z); c.mis_contrib = V(f.w, h.w, hitrec.x);
-    if (AOVS) {
-        const float4 sa = p[8], sn = p[9];
-        c.sumA = V(sa.x, sa.y, sa.z); c.sumN = V(sn.x, sn.y, sn.z);
-    } else { c.sumA = V1(0.0f); c.sumN = V1(0.0f); }
+    c.sumA = V1(0.0f); c.sumN = V1(0.0f);
 }
 
 
@@ -258,9 +254,10 @@ template <bool AOVS> HD void wf_load_ctx(const float4* ctx, uint32_t id, LaneCtx
 // P.wf_refill lanes have no ray at all), i.e. every few iterations instead of every iteration: rays of the bundled scene last 2.5
 // iterations on average, and with the hand-over in every iteration it was 15 % of the kernel's time (profiles/r02_experiments.md).
 // Returns when no lane has a ray, nothing is prefetched and the TRACE queue is empty.
-template <bool STATS, bool SPECULATE, int WIDTH, int BLOCK, int CTXF4, typename ST>
+template <bool STATS, int WIDTH, int BLOCK, typename ST>
 HD void wf_trace_stage(const KParams& P, WfShared* Q, wf_ring_ptr rings, const float4* nodes, const float4* tris, const float4* mats, float4* ctx, ST& stack, unsigned long long* lc, unsigned long long* tdiag)
 {
+    constexpr int CTXF4 = HJR_WF_CTX_F4;
     const uint32_t cap = P.wf_cap;
     const float tmin = 0.001f;
     const f3 cam_o = V(P.cam_pos[0], P.cam_pos[1], P.cam_pos[2]);
@@ -330,63 +327,19 @@ HD void wf_trace_stage(const KParams& P, WfShared* Q, wf_ring_ptr rings, const f
         }
         WF_T(15, 1); WF_T(16, __popcll(__ballot(phase < 2)));
         if (phase < 2) {
-            if constexpr (SPECULATE) {
-            // Speculative while-while (Aila & Laine; used by the layouts that read the BVH from memory: 291.5 -> 271.6 ms on the 1 M-triangle
-            // scene, but 131.7 -> 151.7 ms when the BVH sits in LDS): a lane that reaches its first leaf postpones it and keeps descending with the next
-            // node of its stack until no lane of the wave holds an inner node any more, instead of idling through the other lanes' steps.
-            // The nodes visited meanwhile are tested against the not-yet-shortened hit distance: possibly a few more box tests, the
-            // same result (the closest-hit rule does not depend on the order in which triangles are met).
-            uint32_t leaf = HJR_TRAV_DONE; // postponed leaf (HJR_TRAV_DONE = none)
-            for (;;) {
+            for (;;) { // every lane first descends through inner nodes until it holds a leaf (or is out of work) ...
                 if (!(cur & HJR_LEAF_FLAG)) {
+                    WF_T(11, 1); WF_T(12, __popcll(__ballot(true)));
                     const float tfar = (phase == 0) ? a_tmax : hit.t;
                     const uint32_t nb = node_step<WIDTH, BLOCK, ST>(nodes, cur, R, tmin, tfar, stack, sp);
                     if (STATS) { if (phase == 0) lc[5] += nb; else lc[3] += nb; }
                 }
-                if ((cur & HJR_LEAF_FLAG) && cur != HJR_TRAV_DONE && leaf == HJR_TRAV_DONE) {
-                    leaf = cur;
-                    if (sp > 0) { sp--; cur = stack.get(sp); } else cur = HJR_TRAV_DONE;
-                }
-                if (__ballot(!(cur & HJR_LEAF_FLAG)) == 0ull) break;
+                // ... or until fewer than P.node_min lanes are still descending: those keep their node for the next pass
+                const uint32_t n_inner = (uint32_t)__popcll(__ballot(!(cur & HJR_LEAF_FLAG)));
+                if (n_inner == 0u || n_inner < P.node_min) break;
             }
-            bool done = false;
-            while (leaf != HJR_TRAV_DONE && !done) { // the postponed leaf, then the one the descent stopped at
-                const uint32_t first = leaf & 0x07ffffffu, count = (leaf >> 27) & 15u;
-                const float tri_tmax = (phase == 0) ? a_tmax : 1e16f;
-                for (uint32_t i = 0; i < count; i++) {
-                    const float4* g = tris + (first + i) * HJR_TRI_F4;
-                    const float4 g0 = g[0], g1 = g[1], g2 = g[2];
-                    float t, b1, b2;
-                    if (STATS) { if (phase == 0) lc[6] += 1; else lc[4] += 1; }
-                    if (ray_tri(V(g0.x, g0.y, g0.z), V(g0.w, g1.x, g1.y), V(g1.z, g1.w, g2.x), o, d, tmin, tri_tmax, t, b1, b2)) {
-                        if (phase == 0) { occluded = true; done = true; break; }
-                        const uint32_t prim = f2bits(g2.y);
-                        if (hit.prim == 0xffffffffu || t < hit.t || (t == hit.t && prim < hit.prim)) {
-                            hit.t = t; hit.b1 = b1; hit.b2 = b2; hit.k = first + i; hit.prim = prim;
-                        }
-                    }
-                }
-                leaf = HJR_TRAV_DONE;
-                if (!done && (cur & HJR_LEAF_FLAG) && cur != HJR_TRAV_DONE) {
-                    leaf = cur;
-                    if (sp > 0) { sp--; cur = stack.get(sp); } else cur = HJR_TRAV_DONE;
-                }
-            }
-            if (!done) done = (cur == HJR_TRAV_DONE);
-            if (done) {
-                if (STATS) { if (phase == 0) lc[2] += 1; else lc[1] += 1; }
-                if (phase == 0 && b_valid) { phase = 1; o = fresh ? cam_o : ro; d = db; R = box_ray(o, d); sp = 0; cur = 0; }
-                else finish();
-            }
-            } else {
-            while (!(cur & HJR_LEAF_FLAG)) { // every lane first descends through inner nodes until it holds a leaf (or is out of work) ...
-                WF_T(11, 1); WF_T(12, __popcll(__ballot(true)));
-                const float tfar = (phase == 0) ? a_tmax : hit.t;
-                const uint32_t nb = node_step<WIDTH, BLOCK, ST>(nodes, cur, R, tmin, tfar, stack, sp);
-                if (STATS) { if (phase == 0) lc[5] += nb; else lc[3] += nb; }
-            }
-            bool done = (cur == HJR_TRAV_DONE); // ... then all lanes test their leaf's triangles together
-            if (!done) {
+            bool done = (cur == HJR_TRAV_DONE); // ... then all lanes that hold a leaf test its triangles together
+            if (!done && (cur & HJR_LEAF_FLAG)) {
                 const uint32_t first = cur & 0x07ffffffu, count = (cur >> 27) & 15u;
                 const float tri_tmax = (phase == 0) ? a_tmax : 1e16f;
                 for (uint32_t i = 0; i < count; i++) {
@@ -418,13 +371,12 @@ HD void wf_trace_stage(const KParams& P, WfShared* Q, wf_ring_ptr rings, const f
                     sp = 0; cur = 0;
                 } else finish();
             }
-            }
         }
     }
 }
 
 // ---- SHADE stage: up to 64 contexts of one class: second half of the bounce just traced, first half of the next one
-template <int INTEGRATOR, bool STATS, bool AOVS, int WIDTH, int BLOCK, typename ST>
+template <int INTEGRATOR, bool STATS, bool AOVS, bool TEX, int WIDTH, int BLOCK, typename ST>
 HD void wf_shade_stage(const KParams& P, WfShared* Q, wf_ring_ptr rings, int q, const float4* nodes, const float4* tris, const float4* mats, const float4* lights,
                        float4* ctx, WaveRange& wr, ST& stack, unsigned long long* lc, unsigned long long* tdiag)
 {
@@ -443,7 +395,8 @@ HD void wf_shade_stage(const KParams& P, WfShared* Q, wf_ring_ptr rings, int q, 
     if (have) {
         id = wf_take(rings, q, start + lane, cap);
         float4 hr;
-        wf_load_ctx<AOVS>(ctx, id, c, tracing, hr);
+        wf_load_ctx(ctx, id, c, tracing, hr);
+        if (AOVS) c.aov = P.wf_aov + ((size_t)blockIdx.x * cap + id) * HJR_WF_AOV_F4; // the item's albedo / normal sums live here, not in the record
 #ifdef HJR_WF_TIMING
         __builtin_amdgcn_s_waitcnt(0x0070); // vmcnt(0): the loads have landed
         if (lane == 0u) { WF_T(3, WF_NOW() - t_s0); }
@@ -452,7 +405,7 @@ HD void wf_shade_stage(const KParams& P, WfShared* Q, wf_ring_ptr rings, int q, 
         Hit h;
         h.t = 0.0f; h.b1 = hr.y; h.b2 = hr.z; h.k = kk & 0x7fffffffu; // (the hit distance is not an input of the hit program)
         h.prim = (h.k == WF_MISS) ? 0xffffffffu : f2bits(tris[h.k * HJR_TRI_F4 + 2].y);
-        bounce_post_trace<INTEGRATOR, STATS, AOVS, WIDTH, BLOCK, ST>(P, nodes, tris, mats, lights, c, tracing, (kk >> 31) != 0u, h, stack, lc);
+        bounce_post_trace<INTEGRATOR, STATS, AOVS, TEX, WIDTH, BLOCK, ST>(P, nodes, tris, mats, lights, c, tracing, (kk >> 31) != 0u, h, stack, lc);
     }
     tracing = false;
     bounce_pre_trace<STATS, AOVS>(P, c, wr, have, tracing, lc);
@@ -461,7 +414,7 @@ HD void wf_shade_stage(const KParams& P, WfShared* Q, wf_ring_ptr rings, int q, 
     const bool retry = have && !again && !c.dead;
     const unsigned long long t_st = WF_NOW();
     WF_T(4, 1); WF_T(5, got);
-    if (again || retry) wf_store_ctx<AOVS>(ctx, id, c, tracing);
+    if (again || retry) wf_store_ctx(ctx, id, c, tracing);
     wf_push_trace(Q, rings, again, id, cap);
     wf_push_shade(Q, rings, retry ? id + 1u : 0u, 0u, cap); // class 0
     const uint32_t retired = (uint32_t)__popcll(__ballot(have && !again && !retry)); // no ray and no item left: the context is finished
@@ -472,9 +425,10 @@ HD void wf_shade_stage(const KParams& P, WfShared* Q, wf_ring_ptr rings, int q, 
 // Dynamic LDS: [traversal stacks: stack_lds_entries x BLOCK uint32][scene tables when LDSBVH][WfShared][rings: HJR_WF_QUEUES x wf_cap uint16]
 // SPILL: only the top stack_lds_entries of a lane's traversal stack are in LDS, deeper ones in the HBM overflow buffer (always for the
 // memory layouts; for the LDS-resident layout only when the whole stacks do not fit beside the scene tables and the queues)
-template <int INTEGRATOR, bool STATS, int BLOCK, bool LDSBVH, bool SPILL, int WIDTH, bool AOVS>
+template <int INTEGRATOR, bool STATS, int BLOCK, bool LDSBVH, bool SPILL, int WIDTH, int VAR>
 __global__ void __launch_bounds__(BLOCK, 1) hjr_wavefront_kernel(const KParams P)
 {
+    constexpr bool AOVS = VAR >= 1, TEX = VAR == 2; // as in hjr_render_kernel
     typedef uint32_t SE;
     typedef LaneStack<SE, BLOCK, SPILL, STATS> ST;
     ST stack;
@@ -504,7 +458,7 @@ __global__ void __launch_bounds__(BLOCK, 1) hjr_wavefront_kernel(const KParams P
 #ifdef HJR_WF_WATCHDOG
     if (threadIdx.x == 0u) wf_t0 = __builtin_amdgcn_s_memrealtime();
 #endif
-    constexpr int CTXF4 = AOVS ? HJR_WF_CTX_F4_FULL : HJR_WF_CTX_F4_LEAN;
+    constexpr int CTXF4 = HJR_WF_CTX_F4;
     float4* ctx = P.wf_ctx + (size_t)blockIdx.x * cap * CTXF4;
     for (uint32_t i = threadIdx.x; i < cap * CTXF4; i += BLOCK) // every context starts with all flags clear but `fresh`
         ctx[i] = (i % CTXF4 == 1u) ? make_float4(0.0f, 0.0f, 0.0f, bits2f(WF_FRESH)) : ((i % CTXF4 == 7u) ? make_float4(0.0f, 0.0f, 0.0f, bits2f(WF_MISS)) : make_float4(0.0f, 0.0f, 0.0f, 0.0f));
@@ -568,8 +522,8 @@ __global__ void __launch_bounds__(BLOCK, 1) hjr_wavefront_kernel(const KParams P
         }
         const unsigned long long t_g0 = WF_NOW();
 
-        if (pick == 0u) { wf_trace_stage<STATS, !LDSBVH, WIDTH, BLOCK, CTXF4, ST>(P, Q, rings, nodes, tris, mats, ctx, stack, lc, tdiag); WF_T(8, 1); WF_T(1, WF_NOW() - t_g0); }
-        else { wf_shade_stage<INTEGRATOR, STATS, AOVS, WIDTH, BLOCK, ST>(P, Q, rings, (int)pick, nodes, tris, mats, lights, ctx, wr, stack, lc, tdiag); WF_T(2, WF_NOW() - t_g0); }
+        if (pick == 0u) { wf_trace_stage<STATS, WIDTH, BLOCK, ST>(P, Q, rings, nodes, tris, mats, ctx, stack, lc, tdiag); WF_T(8, 1); WF_T(1, WF_NOW() - t_g0); }
+        else { wf_shade_stage<INTEGRATOR, STATS, AOVS, TEX, WIDTH, BLOCK, ST>(P, Q, rings, (int)pick, nodes, tris, mats, lights, ctx, wr, stack, lc, tdiag); WF_T(2, WF_NOW() - t_g0); }
     }
 #ifdef HJR_WF_TIMING
     if (lane == 0u) for (int i = 0; i < 19; i++) atomicAdd(&wf_diag[i], tdiag[i]);

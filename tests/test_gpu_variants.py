@@ -164,6 +164,22 @@ def test_wavefront_deep_scene(tmp_path):
     assert st["stack_need"] > 16 and st["stack_lds_entries"] == 16
 
 
+@pytest.mark.parametrize("pipe", ["mega", WF])
+@pytest.mark.parametrize("node_min", [1, 64])
+def test_descent_threshold_extremes(cornell, tmp_path, pipe, node_min):
+    """HJR_NODE_MIN (hjr_traverse.hip.h / wf_trace_stage): with 1 the lanes of a wave descend until every lane holds a leaf, with 64 a
+    pass ends after a single node step unless all 64 lanes are still descending, so practically every lane carries an inner node from
+    one pass to the next.  Same bits in both kernel families, for the LDS-resident layout, both memory layouts, the stack overflow
+    path and a deep tree."""
+    env = {"HJR_NODE_MIN": node_min}
+    check_layout(cornell, "cornell", dict(env), expect_mode=1, w=64, h=48, spp=3, pipeline=pipe)
+    check_layout(cornell, "cornell", dict(env, HJR_LDS_BVH=0), expect_mode=0, w=64, h=48, spp=3, pipeline=pipe)
+    check_layout(cornell, "cornell", dict(env, HJR_LDS_BVH=0, HJR_BVH_WIDTH=2, HJR_SHORT_STACK=2), expect_mode=3, w=48, h=32, spp=2,
+                 integrators=(hjr.INTEGRATOR_NEE, hjr.INTEGRATOR_MIS), expect_overflow=True, pipeline=pipe)
+    s = StressScene(tmp_path, spheres=8, segments=88)
+    check_layout(s, "ss8x88", dict(env), expect_mode=0, w=64, h=36, spp=2, integrators=(hjr.INTEGRATOR_NEE,), pipeline=pipe)
+
+
 def test_wavefront_statistics_match_the_megakernel(cornell):
     """Ray / hit / sample counters are properties of the sample streams: both kernel families must report the same numbers."""
     res = {}
@@ -182,7 +198,7 @@ def test_wavefront_statistics_match_the_megakernel(cornell):
 
 def test_pipeline_selection(cornell):
     """Without HJR_PIPELINE the library picks the kernel family per launch (hjr_device.hip::launch): the wavefront kernels for MIS
-    (any layout) and for colour-only NEE on LDS-resident scenes, the megakernel otherwise.  Whatever it picks, the bits are the oracle's."""
+    (any layout), the megakernel otherwise.  Whatever it picks, the bits are the oracle's."""
     old = os.environ.pop("HJR_PIPELINE", None)
     try:
         d = cornell.device()
@@ -190,7 +206,7 @@ def test_pipeline_selection(cornell):
             def pipe(integ, aovs):
                 d.render(cornell.hjr_params(48, 32, 2, integrator=integ), want_aovs=aovs)
                 return d.stats()["pipeline"]
-            assert pipe(hjr.INTEGRATOR_NEE, False) == 1 and pipe(hjr.INTEGRATOR_NEE, True) == 0
+            assert pipe(hjr.INTEGRATOR_NEE, False) == 0 and pipe(hjr.INTEGRATOR_NEE, True) == 0
             assert pipe(hjr.INTEGRATOR_MIS, False) == 1 and pipe(hjr.INTEGRATOR_MIS, True) == 1
             assert pipe(hjr.INTEGRATOR_PT, False) == 0
         finally:

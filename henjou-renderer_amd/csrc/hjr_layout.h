@@ -28,7 +28,9 @@
 #define HJR_NODE2_F4 4
 #endif
 #define HJR_NODE4_F4 7
+#ifndef HJR_BLOCK_LDS
 #define HJR_BLOCK_LDS 1024          /* threads of the one-per-CU workgroup that shares an LDS copy of the BVH (16 waves = 4 per SIMD) */
+#endif
 #define HJR_LDS_BUDGET (159u * 1024u)
 /* Triangle (leaf order), 48 B = 3 x float4: world-space vertices + global prim id.
  *   g0 = (v0.x v0.y v0.z v1.x)  g1 = (v1.y v1.z v2.x v2.y)  g2 = (v2.z, prim_id bits, material_id bits, 0) */

@@ -55,7 +55,7 @@ PMC_PASSES = [  # separate passes: SQ has 8 slots, FETCH_SIZE / WRITE_SIZE do no
 ]
 
 
-def collect_pmc(kbench_args, env=None, timeout=150):
+def collect_pmc(kbench_args, env=None, timeout=150, passes=None):
     """Runs tools/kbench (one warm-up + one measured frame of the bench workload through the same libhenjou_hip.so) under
     `rocprofv3 --pmc`, one pass per counter group, and returns {counter: value per FRAME summed over the product's kernels}.
     The program itself follows `--` (no shell / env / launcher hop).  Raises on any failure: the caller decides what to report."""
@@ -75,7 +75,7 @@ def collect_pmc(kbench_args, env=None, timeout=150):
     e = dict(os.environ)
     e.update(env or {})
     e["TMPDIR"] = "/tmp"
-    for counters in PMC_PASSES:
+    for counters in (passes or PMC_PASSES):
         d = tempfile.mkdtemp(prefix="hjr_pmc_", dir="/tmp")
         try:
             cmd = [rp, "--pmc"] + counters + ["--output-format", "csv", "-d", d, "--", kb] + kbench_args
@@ -99,6 +99,35 @@ def collect_pmc(kbench_args, env=None, timeout=150):
     return out
 
 
+def stress_secondary(lib_path, spheres, segments, env=None):
+    """Secondary block of the default bench line: the generated ~1 M-triangle scene (BVH4 read from L2 / Infinity Cache / HBM instead of
+    LDS) at 1920x1080 x 64 spp NEE through the same library, in tools/kbench child processes: kernel ms from the library's HIP events,
+    fabric bytes from separate FETCH_SIZE / WRITE_SIZE counter passes of the same command."""
+    import re
+    import subprocess
+    import tempfile
+    sdir = os.path.join(tempfile.gettempdir(), "hjr_stress_%d_%d_sec" % (spheres, segments))
+    gen = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_stress_scene.py"), sdir, "--spheres", str(spheres), "--segments", str(segments)],
+                         capture_output=True, text=True, check=True)
+    tri = re.search(r"= (\d+) triangles", gen.stdout)
+    cfg = os.path.join(sdir, "render_option_stress.json")
+    e = dict(os.environ)
+    e.update(env or {})
+    kb = os.path.join(ROOT, "tools", "kbench")
+    r = subprocess.run([kb, lib_path, cfg, "--reps", "3"], cwd=os.path.join(ROOT, "henjou-renderer_amd", "assets"), env=e, capture_output=True, text=True, timeout=300)
+    m = re.search(r" (\d+)x(\d+)x(\d+) integ .*kernel ms min ([0-9.]+) mean ([0-9.]+)", r.stdout)
+    if r.returncode != 0 or not m:
+        raise RuntimeError("kbench on the stress scene failed (rc %d): %s" % (r.returncode, (r.stderr or r.stdout)[-300:]))
+    w, h, spp, ms = int(m.group(1)), int(m.group(2)), int(m.group(3)), float(m.group(5))
+    c = collect_pmc([lib_path, cfg, "--reps", "1"], env=env, timeout=300, passes=[["FETCH_SIZE"], ["WRITE_SIZE"]])
+    traffic = c["FETCH_SIZE"] * 1024.0 * 2.0 + c["WRITE_SIZE"] * 1024.0
+    gbps = traffic / (ms * 1e-3) / 1e9
+    return {"workload": "generated stress scene (%d spheres x %d segments): %dx%d %d spp, NEE, colour only" % (spheres, segments, w, h, spp),
+            "triangles": int(tri.group(1)) if tri else None, "value": round(w * h * spp / (ms * 1e3), 3), "unit": "Msamples/s", "kernel_ms_avg": round(ms, 3),
+            "roofline": {"bound": "hbm", "achieved": round(gbps, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBS, 5), "traffic": int(traffic),
+                         "definition": "(FETCH_SIZE x 2 + WRITE_SIZE) counter bytes per launch / kernel time: fabric-side traffic, the scene (~100 MB) is Infinity-Cache resident"}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -114,6 +143,7 @@ def main():
     ap.add_argument("--stress-segments", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 counter passes (roofline.frac / traffic become null)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary block (1 M-triangle stress scene) of the default line")
     ap.add_argument("--cpu-spp", type=int, default=1024, help="spp of the bounded CPU-baseline sample (the metric's RMSE is quoted at 1024 spp)")
     ap.add_argument("--cpu-threads", type=int, default=int(os.environ.get("HJR_CPU_THREADS", "16")),
                     help="oracle threads for the CPU baseline (a 1-GPU box's CPU share is 16 cores)")
@@ -145,6 +175,12 @@ def main():
             pmc = collect_pmc(kargs, env=penv)
         except Exception as ex:  # reported on the line; never silently replaced by a committed file
             pmc_error = "%s: %s" % (type(ex).__name__, ex)
+    secondary = None
+    if rank == 0 and world == 1 and args.scene == "cornell" and not args.no_pmc and not args.no_secondary and "HJR_BENCH_DEVICE" not in os.environ:
+        try:
+            secondary = stress_secondary(os.environ.get("HJR_LIB") or os.path.join(ROOT, "henjou-renderer_amd", "libhenjou_hip.so"), args.stress_spheres, args.stress_segments)
+        except Exception as ex:
+            secondary = {"error": "%s: %s" % (type(ex).__name__, ex)}
 
     import numpy as np
     import torch
@@ -336,6 +372,8 @@ def main():
             roof.update({"bound": "valu", "achieved": None, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None,
                          "counters": {"source": "not collected", "reason": pmc_error or ("--no-pmc" if args.no_pmc else "rank / rehearsal run")}})
         out["roofline"] = roof
+        if secondary is not None:
+            out["secondary"] = {"large_scene": secondary}
 
         # ---- CPU baseline: the oracle (kind "port": the reference has no CPU path) on a bounded sample of the same
         #      workload: a centred window of the SAME frame (same camera, same resolution) at the metric's 1024 spp.  The same

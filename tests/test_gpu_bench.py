@@ -23,7 +23,8 @@ def run(cmd, env=None):
 
 
 def test_bench_single_gpu_contract():
-    d = run([sys.executable, "bench.py", "--width", "320", "--height", "200", "--spp", "32", "--steps", "2", "--warmup", "1", "--cpu-spp", "2"])
+    d = run([sys.executable, "bench.py", "--width", "320", "--height", "200", "--spp", "32", "--steps", "2", "--warmup", "1", "--cpu-spp", "2",
+             "--stress-spheres", "8", "--stress-segments", "32"])
     for k in REQUIRED:
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["unit"] == "Msamples/s" and d["dtype"] == "f32"
@@ -35,6 +36,10 @@ def test_bench_single_gpu_contract():
     assert 0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert r["traffic"] > 0 and 0 < r["counters"]["active_lane_frac"] <= 1.0
     assert d["color_only"]["value"] > 0
+    big = d["secondary"]["large_scene"]  # the memory-path scene (here a small one) with its measured fabric traffic
+    assert "error" not in big, big
+    assert big["value"] > 0 and big["triangles"] == 12 + 8 * 960 and big["roofline"]["bound"] == "hbm" and big["roofline"]["traffic"] > 0
+    assert 0 < big["roofline"]["frac"] <= 1.0
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "Msamples/s"
     assert c["rmse_gpu_vs_cpu"]["value"] < 1e-3 * 50  # 2 spp here: a smoke value; the 1024-spp bar is checked in test_gpu_parity.py

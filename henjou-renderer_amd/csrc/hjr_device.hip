@@ -353,6 +353,12 @@ template <int I, bool S> static int launch_wf(hjr_ctx* c, const KParams& kp, uin
 #ifndef HJR_NODE_MIN_MEM
 #define HJR_NODE_MIN_MEM 24    /* scenes read from memory (1 M triangles, 1 / 8 / 16 / 24 / 32: megakernel 280 / 197 / 180 / 179 / 190 ms, wavefront 255 / 213 / 194 / 189 / 192) */
 #endif
+#ifndef HJR_HOLD_MIN
+#define HJR_HOLD_MIN 8 /* megakernel: lanes of the rare material class (multiple-scattering GGX) a wave collects before it shades them (0: never hold; C2 with AOVs, 0 / 4 / 8 / 16 / 32: 129.0 / 126.5 / 126.2 / 127.9 / 144.2 ms) */
+#endif
+#ifndef HJR_HOLD_AGE
+#define HJR_HOLD_AGE 2 /* ... or rounds the oldest of them has waited */
+#endif
 template <int I, bool S> static int launch(hjr_ctx* c, const KParams& kp_in, uint64_t n_items, int lds_mode, hipStream_t st)
 {
     KParams kp = kp_in;
@@ -372,6 +378,9 @@ template <int I, bool S> static int launch(hjr_ctx* c, const KParams& kp_in, uin
     // queued at most ~12 times per sample; frames that could bring one workgroup near 2^32 pushes (4x its even share) stay with the megakernel
     if ((double)n_items * kp.chunk_spp * 12.0 * 4.0 / (double)(c->n_cus > 0 ? c->n_cus : 1) >= 4.0e9) wf = false;
     c->stats.pipeline = wf ? 1u : 0u;
+    kp.hold_min = HJR_HOLD_MIN; kp.hold_age = HJR_HOLD_AGE;
+    if (const char* e = getenv("HJR_HOLD_MIN")) { int v = atoi(e); if (v >= 0 && v <= 64) kp.hold_min = (uint32_t)v; } // tuning knobs
+    if (const char* e = getenv("HJR_HOLD_AGE")) { int v = atoi(e); if (v >= 1 && v <= 1000) kp.hold_age = (uint32_t)v; }
     kp.node_min = nm_forced ? nm_forced : (lds_layout ? (wf ? HJR_NODE_MIN_LDS_WF : HJR_NODE_MIN_LDS) : HJR_NODE_MIN_MEM);
     if (wf) {
         const int rc = launch_wf<I, S>(c, kp, n_items, lds_mode, st);

@@ -47,6 +47,7 @@ struct KParams {
     uint32_t spill_stride;           // lanes in the grid
     uint32_t stack_lds_entries;      // memory-path kernels: stack entries per lane kept in LDS (the rest overflow to stack_spill)
     uint32_t node_min;               // descent loop of the fused traversals: lanes still holding an inner node below which a pass moves on to the leaves (hjr_traverse.hip.h)
+    uint32_t hold_min, hold_age;     // megakernel: hits of the rare material class wait until a wave has hold_min of them or one has waited hold_age rounds (0: off)
     float4* wf_ctx;                  // wavefront kernel: context records, [workgroup][wf_cap] x 128 bytes (hjr_wavefront.hip.h)
     float4* wf_aov;                  // wavefront kernel, albedo / normal launches: per-context AOV sums, [workgroup][wf_cap] x 32 bytes
     uint32_t wf_cap;                 // contexts per workgroup (power of two, <= 32768: ids travel as uint16 + 1)

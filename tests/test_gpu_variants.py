@@ -180,6 +180,18 @@ def test_descent_threshold_extremes(cornell, tmp_path, pipe, node_min):
     check_layout(s, "ss8x88", dict(env), expect_mode=0, w=64, h=36, spp=2, integrators=(hjr.INTEGRATOR_NEE,), pipeline=pipe)
 
 
+@pytest.mark.parametrize("hold_min,hold_age", [(0, 1), (2, 1), (64, 9)])
+def test_rare_class_hold_back(cornell, tmp_path, hold_min, hold_age):
+    """HJR_HOLD_MIN / HJR_HOLD_AGE (megakernel, hjr_kernel.hip.h): hits on metallic (multiple-scattering GGX) surfaces wait until a wave
+    holds hold_min of them or one has waited hold_age rounds.  Off, eager (2 / 1) and as lazy as it gets (64 / 9: every such hit waits
+    nine rounds unless nothing else is left): same bits in the LDS-resident layouts (the kernels of the memory layouts do not hold)."""
+    env = {"HJR_HOLD_MIN": hold_min, "HJR_HOLD_AGE": hold_age}
+    check_layout(cornell, "cornell", dict(env), expect_mode=1, w=80, h=56, spp=5)
+    check_layout(cornell, "cornell", dict(env, HJR_LDS_STACK16=1), expect_mode=2, w=64, h=48, spp=3, integrators=(hjr.INTEGRATOR_NEE, hjr.INTEGRATOR_MIS))
+    s = Cornell("render_option_c2_nodiel.json")  # the sphere itself is metallic here: most hits of its tiles are of the held class
+    check_layout(s, "cornell_nodiel", dict(env), expect_mode=1, w=80, h=56, spp=4, integrators=(hjr.INTEGRATOR_NEE,))
+
+
 def test_wavefront_statistics_match_the_megakernel(cornell):
     """Ray / hit / sample counters are properties of the sample streams: both kernel families must report the same numbers."""
     res = {}

@@ -405,10 +405,10 @@ HD void wf_shade_stage(const KParams& P, WfShared* Q, wf_ring_ptr rings, int q, 
         Hit h;
         h.t = 0.0f; h.b1 = hr.y; h.b2 = hr.z; h.k = kk & 0x7fffffffu; // (the hit distance is not an input of the hit program)
         h.prim = (h.k == WF_MISS) ? 0xffffffffu : f2bits(tris[h.k * HJR_TRI_F4 + 2].y);
-        bounce_post_trace<INTEGRATOR, STATS, AOVS, TEX, WIDTH, BLOCK, ST>(P, nodes, tris, mats, lights, c, tracing, (kk >> 31) != 0u, h, stack, lc);
+        bounce_post_trace<INTEGRATOR, STATS, AOVS, TEX, WIDTH, BLOCK, ST, true>(P, nodes, tris, mats, lights, c, tracing, (kk >> 31) != 0u, h, stack, lc);
     }
     tracing = false;
-    bounce_pre_trace<STATS, AOVS>(P, c, wr, have, tracing, lc);
+    bounce_pre_trace<STATS, AOVS, true>(P, c, wr, have, tracing, lc); // (ONEWRITE: one write-out site per pass)
     const bool again = have && (tracing || c.sh_valid);
     // no ray, not dead: the item it took lies outside a ragged frame edge; it takes the next one in another pass (class "path ends")
     const bool retry = have && !again && !c.dead;

@@ -118,17 +118,6 @@ HD float d_Lambda(float a, f3 w) // :58-61
 HD float d_G1(float a, f3 w) { return 1.0f / (1.0f + d_Lambda(a, w)); }                             // :50-52
 HD float d_G2(float a, f3 wi, f3 wo) { return 1.0f / (1.0f + d_Lambda(a, wi) + d_Lambda(a, wo)); }   // :54-56
 HD float d_getPDFDiffuse(f3 wi) { return fabsf(wi.y) * HJ_INV_PI; }                                  // :40-42
-HD f3 d_sampleDiffuse(f2 uv, float& pdf) // :30-38
-{
-    float theta = 0.5f * p_acos(1.0f - 2.0f * uv.x);
-    float phi = 2.0f * HJ_PI * uv.y;
-    float sinTheta, cosTheta, sp, cp;
-    p_sincos(theta, sinTheta, cosTheta);
-    p_sincos(phi, sp, cp);
-    f3 wi = V(cp * sinTheta, cosTheta, sp * sinTheta);
-    pdf = d_getPDFDiffuse(wi);
-    return wi;
-}
 // spherical-cap VNDF sampling (arXiv 2306.05044): disneyBRDF.h:64-80 == BSDFs.h:616-632
 HD f3 sample_visible_normal(float alpha, f2 uv, f3 wo)
 {
@@ -157,18 +146,6 @@ HD float clearcoat_D(f3 wm, float alpha) // :131-139
 HD float d_getPDFClearcoat(f3 wm, f3 wo) // :102-104
 {
     return clearcoat_D(wm, HJ_CLEARCOAT_ALPHA) * fabsf(wm.y) / (4.0f * fabsf(dot(wm, wo)));
-}
-HD f3 d_sampleClearcoat(f2 uv, f3 wo, float& pdf) // :93-100
-{
-    const float ca = HJ_CLEARCOAT_ALPHA;
-    float cosineTheta = sqrtf(fmaxf((1.0f - p_pow(ca * ca, 1.0f - uv.x)) / (1.0f - ca * ca), 0.0f));
-    float sinTheta = sqrtf(fmaxf(1.0f - cosineTheta * cosineTheta, 0.0f));
-    float phi = HJ_PI2 * uv.y;
-    float sp, cp;
-    p_sincos(phi, sp, cp);
-    f3 wm = V(cp * sinTheta, cosineTheta, sp * sinTheta);
-    pdf = d_getPDFClearcoat(wm, wo);
-    return wm;
 }
 HD float f_tSchlick(float wn, float F90) // :106-109
 {
@@ -232,39 +209,38 @@ HD f3 disney_sample(const KParams& P, const Disney& d, f3 wo, f3& wi, float& pdf
     float pdf_diffuse = 1.0f, pdf_specular = 1.0f, pdf_clearcoat = 1.0f;
     f2 xi = cmj_2d(st);
     // The reference's three branches (:262-291) repeat most of their work: the azimuth sin / cos, the normalisation of the half
-    // vector and the three lobe pdfs are the same operations on the lane's own (xi, wi, wm) whichever lobe was chosen.  A wave that
-    // holds lanes of both the diffuse and the specular lobe (two thirds / one third for a dielectric) runs those parts once here
-    // instead of once per branch; each lane still executes exactly the reference's operation sequence on its own values.
-    const bool lobe_diffuse = select_p < dw;
-    if (lobe_diffuse || select_p < dw + sw) {
-        const float phi = 2.0f * HJ_PI * (lobe_diffuse ? xi.y : xi.x); // d_sampleDiffuse :32 / sample_visible_normal :68
-        float sp, cp;
-        p_sincos(phi, sp, cp);
-        f3 v; // the half vector before its normalisation
-        if (lobe_diffuse) { // d_sampleDiffuse (:30-38), then wm = normalize(wi + wo)
-            const float theta = 0.5f * p_acos(1.0f - 2.0f * xi.x);
-            float sinTheta, cosTheta;
-            p_sincos(theta, sinTheta, cosTheta);
-            wi = V(cp * sinTheta, cosTheta, sp * sinTheta);
-            v = wi + wo;
-        } else { // sample_visible_normal (:64-80)
-            const f3 strech_wo = normalize(V(wo.x * d.alpha, wo.y, wo.z * d.alpha));
-            const float z = fmaf((1.0f - xi.y), (1.0f + strech_wo.y), -strech_wo.y);
-            const float sinTheta = sqrtf(clampf(1.0f - z * z, 0.0f, 1.0f));
-            const f3 h = V(cp * sinTheta, z, sp * sinTheta) + strech_wo;
-            v = V(h.x * d.alpha, h.y, h.z * d.alpha);
-        }
-        const f3 wm = normalize(v);
-        if (!lobe_diffuse) wi = reflect3(-wo, wm);
-        pdf_diffuse = d_getPDFDiffuse(wi);
-        pdf_specular = d_getPDFSpecular(d.alpha, wm, wo);
-        pdf_clearcoat = d_getPDFClearcoat(wm, wo);
-    } else {
-        f3 wm = d_sampleClearcoat(xi, wo, pdf_clearcoat);
-        wi = reflect3(-wo, wm);
-        pdf_diffuse = d_getPDFDiffuse(wi);
-        pdf_specular = d_getPDFSpecular(d.alpha, wm, wo);
+    // vector (diffuse and specular lobe) and the three lobe pdfs are the same operations on the lane's own (xi, wi, wm) whichever lobe
+    // was chosen.  A wave that holds lanes of both the diffuse and the specular lobe (two thirds / one third for a dielectric) runs
+    // those parts once here instead of once per branch; each lane still executes exactly the reference's operation sequence on its
+    // own values.  (The clearcoat lobe has weight 0: it is only reached when dw + sw rounds below 1 and select_p falls into the gap.)
+    const int lobe = select_p < dw ? 0 : (select_p < dw + sw ? 1 : 2);
+    const float phi = 2.0f * HJ_PI * (lobe == 1 ? xi.x : xi.y); // d_sampleDiffuse :32, d_sampleClearcoat :97 (HJ_PI2 == 2 HJ_PI) / sample_visible_normal :68
+    float sp, cp;
+    p_sincos(phi, sp, cp);
+    f3 v = V(0.0f, 1.0f, 0.0f), wm = v; // v: the half vector before its normalisation (diffuse, specular)
+    if (lobe == 0) { // d_sampleDiffuse (:30-38), then wm = normalize(wi + wo)
+        const float theta = 0.5f * p_acos(1.0f - 2.0f * xi.x);
+        float sinTheta, cosTheta;
+        p_sincos(theta, sinTheta, cosTheta);
+        wi = V(cp * sinTheta, cosTheta, sp * sinTheta);
+        v = wi + wo;
+    } else if (lobe == 1) { // sample_visible_normal (:64-80)
+        const f3 strech_wo = normalize(V(wo.x * d.alpha, wo.y, wo.z * d.alpha));
+        const float z = fmaf((1.0f - xi.y), (1.0f + strech_wo.y), -strech_wo.y);
+        const float sinTheta = sqrtf(clampf(1.0f - z * z, 0.0f, 1.0f));
+        const f3 h = V(cp * sinTheta, z, sp * sinTheta) + strech_wo;
+        v = V(h.x * d.alpha, h.y, h.z * d.alpha);
+    } else { // d_sampleClearcoat (:93-100): wm as sampled, not normalised again
+        const float ca = HJ_CLEARCOAT_ALPHA;
+        const float cosineTheta = sqrtf(fmaxf((1.0f - p_pow(ca * ca, 1.0f - xi.x)) / (1.0f - ca * ca), 0.0f));
+        const float sinTheta = sqrtf(fmaxf(1.0f - cosineTheta * cosineTheta, 0.0f));
+        wm = V(cp * sinTheta, cosineTheta, sp * sinTheta);
     }
+    if (lobe != 2) wm = normalize(v);
+    if (lobe != 0) wi = reflect3(-wo, wm);
+    pdf_diffuse = d_getPDFDiffuse(wi);
+    pdf_specular = d_getPDFSpecular(d.alpha, wm, wo);
+    pdf_clearcoat = d_getPDFClearcoat(wm, wo);
     pdf = dw * pdf_diffuse + sw * pdf_specular + cw * pdf_clearcoat;
     if (wi.y < 0.0f) { pdf = 1.0f; return V1(0.0f); }
     return disney_eval(P, d, wo, wi);

@@ -153,7 +153,7 @@ typedef struct hjr_stats {
              box_tests_shadow, tri_tests_shadow, shaded_hits, light_samples, nan_samples;
     float    last_kernel_ms;     /* HIP-event time of the last render kernel on its stream */
     uint32_t bvh_nodes, bvh_depth, n_triangles;
-    /* which megakernel layout the current frame data selects (csrc/hjr_device.hip::launch): 0 = BVH4 read from memory,
+    /* which megakernel layout the current frame data selects (csrc/hjr_launch.hip.h::hjr_launch): 0 = BVH4 read from memory,
      * 1 = BVH2 staged in LDS with 32-bit stack entries, 2 = BVH2 in LDS with 16-bit stack entries, 3 = BVH2 read from memory */
     uint32_t lds_mode;
     uint32_t stack_need;         /* worst-case traversal stack entries per lane of the current BVH */

@@ -1,6 +1,6 @@
 """Every shipped kernel layout of both kernel families under a bit-exact parity test (VERDICT r01 task 1).
 
-hjr_device.hip::launch dispatches four layouts (hjr_stats.lds_mode): 0 = BVH4 read from memory, 1 = BVH2 staged in LDS with
+hjr_launch.hip.h::hjr_launch dispatches four layouts (hjr_stats.lds_mode): 0 = BVH4 read from memory, 1 = BVH2 staged in LDS with
 32-bit stack entries, 2 = BVH2 in LDS with 16-bit stack entries, 3 = BVH2 read from memory; the memory-path layouts keep the
 top of a lane's traversal stack in LDS and overflow into an HBM buffer.  The bundled scene only ever selects layout 1, so each
 other layout is forced here (the host-side knobs are read when the frame data is built / the kernel is launched) and checked,
@@ -209,7 +209,7 @@ def test_wavefront_statistics_match_the_megakernel(cornell):
 
 
 def test_pipeline_selection(cornell):
-    """Without HJR_PIPELINE the library picks the kernel family per launch (hjr_device.hip::launch): the wavefront kernels for MIS
+    """Without HJR_PIPELINE the library picks the kernel family per launch (hjr_launch.hip.h::hjr_launch): the wavefront kernels for MIS
     (any layout), the megakernel otherwise.  Whatever it picks, the bits are the oracle's."""
     old = os.environ.pop("HJR_PIPELINE", None)
     try:

@@ -307,7 +307,7 @@ HD void wf_trace_stage(const KParams& P, WfShared* Q, wf_ring_ptr rings, const f
         const uint32_t n_idle = (uint32_t)__popcll(__ballot(phase == 2));
         const unsigned long long m_need = __ballot(!n_valid);
         if (n_idle >= P.wf_refill || (uint32_t)__popcll(m_need) >= P.wf_prefetch_min) {
-            const unsigned long long t_h0 = WF_NOW();
+            [[maybe_unused]] const unsigned long long t_h0 = WF_NOW();
             WF_T(6, 1); WF_T(7, __popcll(__ballot(fin0 != 0u)) + __popcll(__ballot(fin1 != 0u)));
             wf_push_shade(Q, rings, fin0, fin1, cap);
             fin0 = fin1 = 0u;
@@ -380,7 +380,7 @@ template <int INTEGRATOR, bool STATS, bool AOVS, bool TEX, int WIDTH, int BLOCK,
 HD void wf_shade_stage(const KParams& P, WfShared* Q, wf_ring_ptr rings, int q, const float4* nodes, const float4* tris, const float4* mats, const float4* lights,
                        float4* ctx, WaveRange& wr, ST& stack, unsigned long long* lc, unsigned long long* tdiag)
 {
-    const unsigned long long t_s0 = WF_NOW();
+    [[maybe_unused]] const unsigned long long t_s0 = WF_NOW();
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t cap = P.wf_cap;
     uint32_t start = 0;
@@ -412,7 +412,7 @@ HD void wf_shade_stage(const KParams& P, WfShared* Q, wf_ring_ptr rings, int q, 
     const bool again = have && (tracing || c.sh_valid);
     // no ray, not dead: the item it took lies outside a ragged frame edge; it takes the next one in another pass (class "path ends")
     const bool retry = have && !again && !c.dead;
-    const unsigned long long t_st = WF_NOW();
+    [[maybe_unused]] const unsigned long long t_st = WF_NOW();
     WF_T(4, 1); WF_T(5, got);
     if (again || retry) wf_store_ctx(ctx, id, c, tracing);
     wf_push_trace(Q, rings, again, id, cap);
@@ -520,7 +520,7 @@ __global__ void __launch_bounds__(BLOCK, 1) hjr_wavefront_kernel(const KParams P
             WF_T(0, WF_NOW() - t_i0);
             continue;
         }
-        const unsigned long long t_g0 = WF_NOW();
+        [[maybe_unused]] const unsigned long long t_g0 = WF_NOW();
 
         if (pick == 0u) { wf_trace_stage<STATS, WIDTH, BLOCK, ST>(P, Q, rings, nodes, tris, mats, ctx, stack, lc, tdiag); WF_T(8, 1); WF_T(1, WF_NOW() - t_g0); }
         else { wf_shade_stage<INTEGRATOR, STATS, AOVS, TEX, WIDTH, BLOCK, ST>(P, Q, rings, (int)pick, nodes, tris, mats, lights, ctx, wr, stack, lc, tdiag); WF_T(2, WF_NOW() - t_g0); }

@@ -3,13 +3,14 @@
 // same thing.
 //
 // Why: in the megakernel a lane owns its path from the first to the last bounce, so each wave executes the union of what its 64
-// lanes need — rays of very different length in one traversal loop, three material classes in one shading pass.  rocprofv3 on the
-// bundled scene: 35 % of the VALU lanes do useful work while VALU issue is saturated (profiles/r02_*).  Here the 16 waves of the
-// one workgroup per CU share a pool of `wf_cap` path contexts (LaneCtx, parked in HBM / Infinity Cache between stages: 128 bytes
-// per context, the pool of a CU is a few hundred KB) and take work in batches from five queues of 16-bit context ids in LDS:
+// lanes need — rays of very different length in one traversal loop, three material classes in one shading pass: 40 % of the VALU
+// lanes do useful work while VALU issue is saturated (profiles/r02_*).  Here the 16 waves of the one workgroup per CU share a pool
+// of `wf_cap` path contexts (LaneCtx, parked in HBM / Infinity Cache between stages: 128 bytes = one cache line per context, the pool
+// of a CU is a few hundred KB) and take work in batches from five queues of 16-bit context ids in LDS:
 //   * queue 0, TRACE: contexts with rays to trace (the pending NEE shadow ray of the bounce shaded last + the next closest-hit
-//     ray, as in the megakernel's fused traversal).  A wave traces 64 of them; lanes that finish hand their result over and take
-//     the next context as soon as HJR_WF_REFILL lanes are waiting, so ray-length variance no longer idles lanes;
+//     ray, as in the megakernel's fused traversal).  A wave traces 64 of them; a lane whose rays are done notes the result and starts
+//     the context it holds prefetched at once (lane-local), and every few passes the wave hands the finished contexts over and takes
+//     new ones, so ray-length variance no longer idles lanes;
 //   * queues 1..4, SHADE by the class of what the closest-hit ray found (path ends: miss / light; Disney; multiple-scattering
 //     GGX; glass).  A wave takes up to 64 contexts of ONE class, runs bounce_post_trace + bounce_pre_trace on them (wave-uniform
 //     branches in practice) and queues them for TRACE again.  The class only decides which lanes run together, never what a lane
@@ -18,6 +19,9 @@
 // queue), so the pool stays full until the frame runs out of work; a context with nothing left is retired, and the waves leave
 // when the live count reaches zero.  All synchronisation is workgroup-local (LDS atomics + workgroup-scope fences): one
 // workgroup is one CU, no cross-CU protocol is involved.
+// What it buys (profiles/r02_experiments.md): 50 % active lanes and 20 % fewer VALU instructions than the megakernel, paid back in waits
+// at the stage boundaries.  It wins where the shading pass is long — MIS: 187 vs 222 ms on the bundled scene, 417 vs 635 ms on 1 M
+// triangles — and hjr_launch() selects it there; NEE and Pathtrace run faster on the megakernel.
 #pragma once
 #include "hjr_kernel.hip.h"
 

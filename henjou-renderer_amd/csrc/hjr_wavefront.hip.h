@@ -26,7 +26,7 @@
 #include "hjr_kernel.hip.h"
 
 #ifndef HJR_WF_REFILL
-#define HJR_WF_REFILL 16 /* trace stage: lanes waiting (finished or empty) before the wave stops to report / refill */
+#define HJR_WF_REFILL 16 /* trace stage: lanes without a ray (nothing prefetched either) before the wave stops for a hand-over */
 #endif
 #ifndef HJR_WF_PREFETCH_MIN
 #define HJR_WF_PREFETCH_MIN 32 /* trace stage: lanes that have used up their prefetched context before the wave stops for a hand-over */

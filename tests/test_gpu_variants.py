@@ -208,6 +208,22 @@ def test_wavefront_statistics_match_the_megakernel(cornell):
         assert res["mega"][k] == res[WF][k], (k, res["mega"][k], res[WF][k])
 
 
+def test_full_size_frames_agree_between_the_families(cornell):
+    """The bench size (1920x1080; 48 spp = six sample runs per pixel): the megakernel's and the wavefront kernel's frames are the same bits
+    for NEE and MIS.  (The first queue protocol of the wavefront kernel was correct on small frames and lost entries from ~30 M samples on.)"""
+    for integ in (hjr.INTEGRATOR_NEE, hjr.INTEGRATOR_MIS):
+        frames = {}
+        for pipe in ("mega", WF):
+            with knobs(HJR_PIPELINE=pipe):
+                d = cornell.device()
+                try:
+                    frames[pipe], _, _ = d.render(cornell.hjr_params(1920, 1080, 48, integrator=integ), want_aovs=False)
+                    assert d.stats()["pipeline"] == {"mega": 0, WF: 1}[pipe]
+                finally:
+                    d.close()
+        assert_bitexact(frames["mega"], frames[WF], "integrator %d at 1920x1080x48" % integ)
+
+
 def test_pipeline_selection(cornell):
     """Without HJR_PIPELINE the library picks the kernel family per launch (hjr_launch.hip.h::hjr_launch): the wavefront kernels for MIS
     (any layout), the megakernel otherwise.  Whatever it picks, the bits are the oracle's."""

@@ -10,6 +10,8 @@ Scene, BVH and all buffers are resident in HBM before the timed region.
     python bench.py [--gpus N] [--steps K] [--warmup W] [--width 1920 --height 1080 --spp 256]
     N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
                 bench.py --gpus N --steps K --warmup W
+            or plainly `python bench.py --gpus N ...`: without WORLD_SIZE in the environment bench.py starts that launcher itself as a
+            child process (before anything touches the GPU), relays its output and exits with its code.
 
 Prints ONE JSON line on rank 0 (contract in the task statement).  `value` is the rate of the launch the reference's raygen
 performs (colour + albedo + normal AOVs, renderer/renderer.h:1222-1224); `color_only` carries the rate of the lean colour-only
@@ -149,6 +151,21 @@ def main():
                     help="oracle threads for the CPU baseline (a 1-GPU box's CPU share is 16 cores)")
     args = ap.parse_args()
 
+    # ---- started plainly with --gpus N > 1: become the launcher.  One rank process per GPU through torch.distributed.run, as a CHILD
+    #      process (never an exec of this one), before torch is imported or the GPU is touched; rank 0 of the child prints the JSON line
+    #      on the inherited stdout.  Under torchrun (WORLD_SIZE set) this block is skipped.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        import subprocess
+        with socket.socket() as sk:  # a free rendezvous port on the loopback interface
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.run(cmd, env=env).returncode)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -188,9 +205,7 @@ def main():
     import __graft_entry__ as entry
     hjr = entry.load_package()
 
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+    if world != args.gpus:  # under a launcher the launcher's world size is the fact
         args.gpus = world
     # rehearsal knobs (never set by the driver): HJR_BENCH_DEVICE pins every rank to one GPU and HJR_BENCH_BACKEND=gloo swaps
     # RCCL for gloo, so that the N > 1 code path can be exercised on a 1-GPU box

@@ -47,10 +47,18 @@ class Texture(C.Structure):
                 ("_reserved", C.c_int32)]
 
 
-class SceneView(C.Structure):
-    _fields_ = [("n_vertices", C.c_uint32), ("n_triangles", C.c_uint32), ("n_instances", C.c_uint32),
+class _Sized(C.Structure):
+    """Sized struct of the C-ABI (include/henjou_hip.h): struct_size = sizeof(this struct), set on construction (HJR_INIT)."""
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.struct_size = C.sizeof(self)
+
+
+class SceneView(_Sized):
+    _fields_ = [("struct_size", C.c_uint32), ("n_vertices", C.c_uint32), ("n_triangles", C.c_uint32), ("n_instances", C.c_uint32),
                 ("n_materials", C.c_uint32), ("n_lights", C.c_uint32), ("n_animations", C.c_uint32),
-                ("n_textures", C.c_uint32), ("_reserved0", C.c_uint32),
+                ("n_textures", C.c_uint32),
                 ("vertices", C.c_void_p), ("normals", C.c_void_p), ("texcoords", C.c_void_p),
                 ("indices", C.c_void_p), ("material_ids", C.c_void_p), ("prim_offset", C.c_void_p),
                 ("geometry_index_offset", C.c_void_p), ("geometry_index_count", C.c_void_p),
@@ -58,8 +66,8 @@ class SceneView(C.Structure):
                 ("light_prim_ids", C.c_void_p), ("light_prim_emission", C.c_void_p), ("textures", C.c_void_p)]
 
 
-class RenderOption(C.Structure):
-    _fields_ = [("image_width", C.c_uint32), ("image_height", C.c_uint32), ("image_name", C.c_char * 256),
+class RenderOption(_Sized):
+    _fields_ = [("struct_size", C.c_uint32), ("image_width", C.c_uint32), ("image_height", C.c_uint32), ("image_name", C.c_char * 256),
                 ("image_directory", C.c_char * 512), ("max_spp", C.c_uint32), ("gltf_path", C.c_char * 512),
                 ("gltf_name", C.c_char * 256), ("fps", C.c_uint32), ("start_frame", C.c_uint32),
                 ("end_frame", C.c_uint32), ("time_limit", C.c_float), ("allow_camera_animation", C.c_int32),
@@ -80,24 +88,27 @@ class Camera(C.Structure):
                 "f": float(self.f)}
 
 
-class Params(C.Structure):
-    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("spp", C.c_uint32), ("frame", C.c_uint32),
+class Params(_Sized):
+    _fields_ = [("struct_size", C.c_uint32), ("width", C.c_uint32), ("height", C.c_uint32), ("spp", C.c_uint32), ("frame", C.c_uint32),
                 ("seed", C.c_uint32), ("integrator", C.c_uint32), ("camera", Camera), ("sky", C.c_float * 3),
                 ("ibl_intensity", C.c_float), ("rank", C.c_uint32), ("world_size", C.c_uint32),
-                ("flags", C.c_uint32), ("_reserved", C.c_uint32)]
+                ("flags", C.c_uint32)]
 
 
-class Stats(C.Structure):
-    _fields_ = [(n, C.c_uint64) for n in ("samples", "closest_rays", "shadow_rays", "box_tests_closest",
+class Stats(_Sized):
+    _fields_ = [("struct_size", C.c_uint32), ("_pad0", C.c_uint32)] + [(n, C.c_uint64) for n in ("samples", "closest_rays", "shadow_rays", "box_tests_closest",
                                            "tri_tests_closest", "box_tests_shadow", "tri_tests_shadow",
                                            "shaded_hits", "light_samples", "nan_samples")] + \
                [("last_kernel_ms", C.c_float), ("bvh_nodes", C.c_uint32), ("bvh_depth", C.c_uint32),
                 ("n_triangles", C.c_uint32), ("lds_mode", C.c_uint32), ("stack_need", C.c_uint32),
-                ("stack_lds_entries", C.c_uint32), ("pipeline", C.c_uint32), ("stack_overflow_pushes", C.c_uint64)]
+                ("stack_lds_entries", C.c_uint32), ("pipeline", C.c_uint32), ("stack_overflow_pushes", C.c_uint64),
+                ("nan_located", C.c_uint32), ("_pad1", C.c_uint32), ("nan_where", (C.c_uint32 * 3) * 8)]
 
     def as_dict(self):
-        return {n: (float(getattr(self, n)) if n == "last_kernel_ms" else int(getattr(self, n)))
-                for n, _ in self._fields_}
+        d = {n: (float(getattr(self, n)) if n == "last_kernel_ms" else int(getattr(self, n)))
+             for n, _ in self._fields_ if n not in ("struct_size", "_pad0", "_pad1", "nan_where")}
+        d["nan_where"] = [tuple(int(v) for v in self.nan_where[i]) for i in range(int(self.nan_located))]  # (x, y, sample)
+        return d
 
 
 _lib = None
@@ -431,11 +442,12 @@ def make_params(width, height, spp, camera, frame=1, seed=1, integrator=INTEGRAT
 
 
 def owned_tile_mask(width, height, rank, world_size, tile=8):
-    """Boolean [height, width] mask of the pixels rank `rank` renders (8x8 tiles dealt round-robin)."""
+    """Boolean [height, width] mask of the pixels rank `rank` renders: 8x8 tiles, tile (tx, ty) has id ty * tiles_x + (tx + ty) % tiles_x
+    (rows rotated so that a rank's tiles run along diagonals, csrc/hjr_layout.h) and belongs to rank id % world_size."""
     tx = (np.arange(width) // tile)[None, :]
     ty = (np.arange(height) // tile)[:, None]
     tiles_x = (width + tile - 1) // tile
-    return ((ty * tiles_x + tx) % world_size) == rank
+    return ((ty * tiles_x + (tx + ty) % tiles_x) % world_size) == rank
 
 
 def exchange_framebuffer(fb, dst=0):

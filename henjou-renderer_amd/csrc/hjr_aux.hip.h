@@ -20,7 +20,8 @@ __global__ void __launch_bounds__(64) hjr_classify_tiles_kernel(const KParams P)
     uint32_t n_cls[4] = { 0u, 0u, 0u, 0u }; // per block; one atomic per class at the end (32 k atomics on four words cost 0.4 ms)
     for (uint32_t idx = blockIdx.x; idx < P.n_owned_tiles; idx += gridDim.x) {
         const uint32_t tile = idx * P.world + P.rank;
-        const uint32_t tx = tile % P.tiles_x, ty = tile / P.tiles_x;
+        uint32_t tx, ty;
+        hjr_tile_xy(tile, P.tiles_x, &tx, &ty);
         const uint32_t px = tx * HJR_TILE + (threadIdx.x & 7u), py = ty * HJR_TILE + (threadIdx.x >> 3);
         uint32_t cls = 0;
         if (px < P.width && py < P.height) {
@@ -116,7 +117,9 @@ __global__ void __launch_bounds__(256) hjr_finalize_kernel(const KParams P)
     const float inv_spp = 1.0f / (float)P.spp;
     for (size_t sl = (size_t)blockIdx.x * blockDim.x + threadIdx.x; sl < n_slots; sl += (size_t)gridDim.x * blockDim.x) {
         const uint32_t tile = (uint32_t)(sl >> 6) * P.world + P.rank;
-        const uint32_t x = (tile % P.tiles_x) * HJR_TILE + ((uint32_t)sl & 7u), y = (tile / P.tiles_x) * HJR_TILE + (((uint32_t)sl >> 3) & 7u);
+        uint32_t tx, ty;
+        hjr_tile_xy(tile, P.tiles_x, &tx, &ty);
+        const uint32_t x = tx * HJR_TILE + ((uint32_t)sl & 7u), y = ty * HJR_TILE + (((uint32_t)sl >> 3) & 7u);
         if (x >= P.width || y >= P.height) continue;
         const size_t pix = P.packed ? sl : (size_t)y * P.width + x;
         float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f), b = a, c = a;
@@ -138,7 +141,9 @@ __global__ void __launch_bounds__(256) hjr_pack_tiles_kernel(const float4* frame
     const size_t sl = (size_t)blockIdx.x * 256u + threadIdx.x;
     if (sl >= (size_t)n_owned * 64u) return;
     const uint32_t tile = (uint32_t)(sl >> 6) * world + rank;
-    const uint32_t x = (tile % tiles_x) * HJR_TILE + ((uint32_t)sl & 7u), y = (tile / tiles_x) * HJR_TILE + (((uint32_t)sl >> 3) & 7u);
+    uint32_t tx, ty;
+    hjr_tile_xy(tile, tiles_x, &tx, &ty);
+    const uint32_t x = tx * HJR_TILE + ((uint32_t)sl & 7u), y = ty * HJR_TILE + (((uint32_t)sl >> 3) & 7u);
     packed[sl] = (x < width && y < height) ? frame[(size_t)y * width + x] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 }
 __global__ void __launch_bounds__(256) hjr_unpack_tiles_kernel(const float4* packed, float4* frame, uint32_t width, uint32_t height, uint32_t tiles_x, uint32_t n_owned, uint32_t rank, uint32_t world)
@@ -146,6 +151,8 @@ __global__ void __launch_bounds__(256) hjr_unpack_tiles_kernel(const float4* pac
     const size_t sl = (size_t)blockIdx.x * 256u + threadIdx.x;
     if (sl >= (size_t)n_owned * 64u) return;
     const uint32_t tile = (uint32_t)(sl >> 6) * world + rank;
-    const uint32_t x = (tile % tiles_x) * HJR_TILE + ((uint32_t)sl & 7u), y = (tile / tiles_x) * HJR_TILE + (((uint32_t)sl >> 3) & 7u);
+    uint32_t tx, ty;
+    hjr_tile_xy(tile, tiles_x, &tx, &ty);
+    const uint32_t x = tx * HJR_TILE + ((uint32_t)sl & 7u), y = ty * HJR_TILE + (((uint32_t)sl >> 3) & 7u);
     if (x < width && y < height) frame[(size_t)y * width + x] = packed[sl];
 }

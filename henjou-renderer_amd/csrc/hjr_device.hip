@@ -15,6 +15,7 @@
 #include "../../include/henjou_hip.h"
 #include "../host/frame.hpp"
 #include "hjr_launch.hip.h"
+#include "../host/abi.hpp"
 #include "hjr_aux.hip.h"
 #include "hjr_denoise.hip.h"
 
@@ -77,6 +78,9 @@ extern "C" void hjr_destroy(hjr_ctx* c)
 extern "C" int hjr_upload_scene(hjr_ctx* c, const hjr_scene_view* v)
 {
     if (!c || !v) { set_error("hjr_upload_scene: null argument"); return HJR_ERR_ARG; }
+    hjr_scene_view view; // sized struct: only the bytes the caller owns are read
+    if (!hjr::abi_take(v, view, "hjr_upload_scene")) return HJR_ERR_ARG;
+    v = &view;
     std::string err;
     if (!c->scene.set(*v, err)) { set_error("hjr_upload_scene: " + err); return HJR_ERR_ARG; }
     HIPCHK(hipSetDevice(c->device));
@@ -198,16 +202,23 @@ extern "C" int hjr_set_sky(hjr_ctx* c, const float* rgba, int w, int h)
 }
 
 // the render kernels live in their own translation units (hjr_launch.hip.h)
+#ifndef HJR_LEAN_VARIANT
 extern template int hjr_launch<HJR_INTEGRATOR_NEE, false>(hjr_ctx*, const KParams&, uint64_t, int, hipStream_t);
 extern template int hjr_launch<HJR_INTEGRATOR_NEE, true>(hjr_ctx*, const KParams&, uint64_t, int, hipStream_t);
 extern template int hjr_launch<HJR_INTEGRATOR_PT, false>(hjr_ctx*, const KParams&, uint64_t, int, hipStream_t);
 extern template int hjr_launch<HJR_INTEGRATOR_PT, true>(hjr_ctx*, const KParams&, uint64_t, int, hipStream_t);
 extern template int hjr_launch<HJR_INTEGRATOR_MIS, false>(hjr_ctx*, const KParams&, uint64_t, int, hipStream_t);
 extern template int hjr_launch<HJR_INTEGRATOR_MIS, true>(hjr_ctx*, const KParams&, uint64_t, int, hipStream_t);
+#endif
 #ifdef HJR_UNITY /* diagnostic variants (make variant): one translation unit, so that the __device__ diagnostic counters are one symbol */
+#ifdef HJR_LEAN_VARIANT /* NEE without the statistics counters only; every other launch runs that kernel too (timing experiments, not pictures) */
+#include "hjr_launch.hip.h"
+template int hjr_launch<HJR_INTEGRATOR_NEE, false>(hjr_ctx*, const KParams&, uint64_t, int, hipStream_t);
+#else
 #include "hjr_launch_nee.hip"
 #include "hjr_launch_pt.hip"
 #include "hjr_launch_mis.hip"
+#endif
 #endif
 
 static int render_impl(hjr_ctx* c, const hjr_params* p, void* d_color, void* d_albedo, void* d_normal, hipStream_t st)
@@ -231,7 +242,8 @@ static int render_impl(hjr_ctx* c, const hjr_params* p, void* d_color, void* d_a
     if (n_items >= 0xffffffffull - (1ull << 24)) { set_error("hjr_render: image too large (more than 2^32 - 2^24 work items per launch)"); return HJR_ERR_ARG; }
 
     // work area: [0] queue head, [16..] HJR_NSTAT uint64 counters
-    const size_t work_bytes = 16 + (HJR_NSTAT + 20) * 8 + 32 + 512; // +20: phase clocks / lane-occupancy sums of the HJR_TIMING diagnostic build; +32: tile-class counters
+    const size_t nan_list_at = 16 + (HJR_NSTAT + 20) * 8 + 32 + 512;
+    const size_t work_bytes = nan_list_at + (1 + HJR_NAN_LIST) * 8; // +20: phase clocks / lane-occupancy sums of the HJR_TIMING diagnostic build; +32: tile-class counters
     if (c->d_work.cap < work_bytes) {
         std::vector<unsigned char> z(work_bytes, 0);
         if (!c->d_work.upload(z.data(), work_bytes, st)) { set_error("hjr_render: work buffer allocation failed"); return HJR_ERR_DEVICE; }
@@ -280,6 +292,7 @@ static int render_impl(hjr_ctx* c, const hjr_params* p, void* d_color, void* d_a
     kp.aov_color = (float4*)d_color; kp.aov_albedo = (float4*)d_albedo; kp.aov_normal = (float4*)d_normal;
     kp.queue_head = (unsigned int*)c->d_work.p;
     kp.stats = (unsigned long long*)((char*)c->d_work.p + 16);
+    kp.nan_list = (unsigned long long*)((char*)c->d_work.p + nan_list_at);
     kp.n_lights = c->frame.n_lights;
     kp.width = p->width; kp.height = p->height; kp.spp = p->spp; kp.frame = p->frame; kp.seed = p->seed; kp.integrator = p->integrator;
     kp.tiles_x = tiles_x; kp.n_owned_items = (uint32_t)n_items;
@@ -357,6 +370,9 @@ static int render_impl(hjr_ctx* c, const hjr_params* p, void* d_color, void* d_a
         kp.tile_order = (const uint32_t*)c->d_tiles.p;
     }
     int lrc = 0;
+#ifdef HJR_LEAN_VARIANT
+    lrc = hjr_launch<HJR_INTEGRATOR_NEE, false>(c, kp, n_items, lds_mode, st);
+#else
     switch (p->integrator * 2 + (stats ? 1 : 0)) {
     case 0: lrc = hjr_launch<HJR_INTEGRATOR_NEE, false>(c, kp, n_items, lds_mode, st); break;
     case 1: lrc = hjr_launch<HJR_INTEGRATOR_NEE, true>(c, kp, n_items, lds_mode, st); break;
@@ -365,6 +381,7 @@ static int render_impl(hjr_ctx* c, const hjr_params* p, void* d_color, void* d_a
     case 4: lrc = hjr_launch<HJR_INTEGRATOR_MIS, false>(c, kp, n_items, lds_mode, st); break;
     default: lrc = hjr_launch<HJR_INTEGRATOR_MIS, true>(c, kp, n_items, lds_mode, st); break;
     }
+#endif
     if (lrc != 0) { set_error("hjr_render: could not reserve dynamic LDS for the BVH"); return HJR_ERR_DEVICE; }
     HIPCHK(hipGetLastError());
     if (n_chunks > 1) {
@@ -386,6 +403,16 @@ static int fetch_stats(hjr_ctx* c, hipStream_t st)
     uint64_t* dst = &c->stats.samples;
     for (int i = 0; i < 10; i++) dst[i] = h[i];
     c->stats.stack_overflow_pushes = h[10];
+    {
+        unsigned long long nl[1 + HJR_NAN_LIST];
+        HIPCHK(hipMemcpy(nl, (char*)c->d_work.p + 16 + (HJR_NSTAT + 20) * 8 + 32 + 512, sizeof(nl), hipMemcpyDeviceToHost));
+        const uint32_t n = (uint32_t)std::min<unsigned long long>(nl[0], HJR_NAN_LIST);
+        c->stats.nan_located = n;
+        for (uint32_t i = 0; i < HJR_NAN_LIST; i++) {
+            const unsigned long long k = i < n ? nl[1 + i] : 0ull;
+            c->stats.nan_where[i][0] = (uint32_t)(k & 0x1fffu); c->stats.nan_where[i][1] = (uint32_t)((k >> 13) & 0x1fffu); c->stats.nan_where[i][2] = (uint32_t)(k >> 26);
+        }
+    }
 #ifdef HJR_WF_TIMING
     { // diagnostic build only: where the waves of the wavefront kernel spend their clocks
         unsigned long long d[24];
@@ -420,19 +447,27 @@ static int fetch_stats(hjr_ctx* c, hipStream_t st)
 #endif
 #ifdef HJR_TIMING
     { // diagnostic build only: wave-clock shares of the megakernel's loop phases and lane occupancies
-        unsigned long long tk[8];
+        unsigned long long tk[18];
         HIPCHK(hipMemcpy(tk, (char*)c->d_work.p + 16 + HJR_NSTAT * 8, sizeof(tk), hipMemcpyDeviceToHost));
         const double tot = (double)tk[0] + (double)tk[1] + (double)tk[2];
         if (tot > 0) fprintf(stderr, "[hjr timing] roulette/refill/regeneration %.1f%%  fused trace %.1f%%  resolve + hit program + shading %.1f%%  (%.3g wave-clocks)\n",
                              100 * tk[0] / tot, 100 * tk[1] / tot, 100 * tk[2] / tot, tot);
         if (tk[3]) fprintf(stderr, "[hjr timing] lanes per round: closest-hit ray %.1f, shadow ray %.1f, serviced %.1f\n", (double)tk[4] / tk[3], (double)tk[5] / tk[3], (double)tk[6] / tk[3]);
+        const unsigned long long* td = tk + 7;
+        if (td[0]) fprintf(stderr, "[hjr timing] traversal: %.1f passes per round, %.1f lanes with a ray per pass (%.1f on a shadow ray); node steps %.2f wave-iterations per pass x %.1f lanes; "
+                                   "leaf parts in %.0f%% of the passes x %.1f lanes; triangle tests %.2f wave-iterations per pass x %.1f lanes\n",
+                           tk[3] ? (double)td[0] / tk[3] : 0.0, (double)td[1] / td[0], (double)td[8] / td[0], (double)td[2] / td[0], td[2] ? (double)td[3] / td[2] : 0.0,
+                           100.0 * td[4] / td[0], td[4] ? (double)td[5] / td[4] : 0.0, (double)td[6] / td[0], td[6] ? (double)td[7] / td[6] : 0.0);
     }
 #endif
     return HJR_OK;
 }
 
-extern "C" int hjr_render_device(hjr_ctx* c, const hjr_params* p, void* d_color, void* d_albedo, void* d_normal, void* stream)
+extern "C" int hjr_render_device(hjr_ctx* c, const hjr_params* p_user, void* d_color, void* d_albedo, void* d_normal, void* stream)
 {
+    hjr_params params; // sized struct
+    if (!c || !hjr::abi_take(p_user, params, "hjr_render_device")) { if (!c) set_error("hjr_render_device: null context"); return HJR_ERR_ARG; }
+    const hjr_params* p = &params;
     if (!c) { set_error("hjr_render_device: null context"); return HJR_ERR_ARG; }
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
     return render_impl(c, p, d_color, d_albedo, d_normal, st);
@@ -508,8 +543,11 @@ extern "C" int hjr_denoise(hjr_ctx* c, int render_mode, uint32_t in_w, uint32_t 
 
 // One frame of Renderer's loop in a Denoise mode, on the device: optixLaunch -> denoise -> cpyGPUBufferToHost(AOV_Output)
 // (renderer.h:1229-1281).  p->width x p->height is the RENDER size (already halved by the caller for DenoiseUpScale2X).
-extern "C" int hjr_render_denoised(hjr_ctx* c, const hjr_params* p, int render_mode, float* out, uint32_t out_w, uint32_t out_h)
+extern "C" int hjr_render_denoised(hjr_ctx* c, const hjr_params* p_user, int render_mode, float* out, uint32_t out_w, uint32_t out_h)
 {
+    hjr_params params; // sized struct
+    if (!c || !hjr::abi_take(p_user, params, "hjr_render_denoised")) { if (!c) set_error("hjr_render_denoised: null context"); return HJR_ERR_ARG; }
+    const hjr_params* p = &params;
     if (!c || !p || !out) { set_error("hjr_render_denoised: null argument"); return HJR_ERR_ARG; }
     HIPCHK(hipSetDevice(c->device));
     const size_t in_bytes = (size_t)p->width * p->height * 16, out_bytes = (size_t)out_w * out_h * 16;
@@ -580,6 +618,8 @@ extern "C" int hjr_synchronize(hjr_ctx* c)
 extern "C" int hjr_get_stats(hjr_ctx* c, hjr_stats* out)
 {
     if (!c || !out) { set_error("hjr_get_stats: null argument"); return HJR_ERR_ARG; }
+    uint32_t out_size;
+    if (!hjr::abi_size(out, out_size, "hjr_get_stats")) return HJR_ERR_ARG;
     HIPCHK(hipSetDevice(c->device));
     if (c->event_pending) {
         HIPCHK(hipEventSynchronize(c->ev1));
@@ -589,17 +629,22 @@ extern "C" int hjr_get_stats(hjr_ctx* c, hjr_stats* out)
         c->event_pending = false;
         if (c->d_work.p) { int rc = fetch_stats(c, c->stream); if (rc != HJR_OK) return rc; }
     }
-    *out = c->stats;
-    return HJR_OK;
+    return hjr::abi_give(out, c->stats, "hjr_get_stats") ? HJR_OK : HJR_ERR_ARG; // sized struct: at most out->struct_size bytes are written
 }
 
-extern "C" int hjr_render(hjr_ctx* c, const hjr_params* p, float* color, float* albedo, float* normal)
+extern "C" int hjr_render(hjr_ctx* c, const hjr_params* p_user, float* color, float* albedo, float* normal)
 {
-    if (!c || !p || !color) { set_error("hjr_render: null argument"); return HJR_ERR_ARG; }
+    if (!c || !p_user || !color) { set_error("hjr_render: null argument"); return HJR_ERR_ARG; }
+    hjr_params params; // sized struct
+    if (!hjr::abi_take(p_user, params, "hjr_render")) return HJR_ERR_ARG;
+    const hjr_params* p = &params;
     HIPCHK(hipSetDevice(c->device));
-    const size_t bytes = (size_t)p->width * p->height * 16;
-    if (bytes == 0) { set_error("hjr_render: empty image"); return HJR_ERR_ARG; }
-    if (p->flags & HJR_FLAG_PACKED) { set_error("hjr_render: HJR_FLAG_PACKED is a device-buffer layout (hjr_render_device)"); return HJR_ERR_ARG; }
+    if ((size_t)p->width * p->height == 0) { set_error("hjr_render: empty image"); return HJR_ERR_ARG; }
+    // HJR_FLAG_PACKED: the buffers hold this rank's tiles only (hjr_owned_tiles x 64 float4), as in hjr_render_device
+    const bool packed_out = (p->flags & HJR_FLAG_PACKED) != 0;
+    if (p->rank >= (p->world_size ? p->world_size : 1u)) { set_error("hjr_render: rank >= world_size"); return HJR_ERR_ARG; }
+    const size_t bytes = packed_out ? (size_t)hjr_owned_tiles(p->width, p->height, p->rank, p->world_size ? p->world_size : 1u) * 64u * 16u : (size_t)p->width * p->height * 16;
+    if (bytes == 0) return HJR_OK; // a rank without tiles
     DevBuf* bufs[3] = { &c->d_color, &c->d_albedo, &c->d_normal };
     float* host[3] = { color, albedo, normal };
     for (int i = 0; i < 3; i++) {
@@ -609,7 +654,7 @@ extern "C" int hjr_render(hjr_ctx* c, const hjr_params* p, float* color, float* 
             if (hipMalloc(&bufs[i]->p, bytes) != hipSuccess) { set_error("hjr_render: AOV allocation failed"); return HJR_ERR_DEVICE; }
             bufs[i]->cap = bytes;
         }
-        HIPCHK(hipMemsetAsync(bufs[i]->p, 0, bytes, c->stream));
+        if (!packed_out) HIPCHK(hipMemsetAsync(bufs[i]->p, 0, bytes, c->stream));
     }
     int rc = render_impl(c, p, c->d_color.p, albedo ? c->d_albedo.p : nullptr, normal ? c->d_normal.p : nullptr, c->stream);
     if (rc != HJR_OK) return rc;

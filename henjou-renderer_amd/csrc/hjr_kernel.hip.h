@@ -277,10 +277,17 @@ HD void shared_claim(const KParams& P, SharedRange* S, uint32_t n, uint32_t& a0,
 }
 
 // NaN/Inf guard + ordered accumulation of one finished sample
-template <bool STATS> HD void finish_sample(LaneCtx& c, f3 L, unsigned long long* lc)
+template <bool STATS> HD void finish_sample(const KParams& P, LaneCtx& c, f3 L, unsigned long long* lc, const uint32_t s_back = 0u) // s_back = 1: the sample before c.s (its bookkeeping was closed while the shadow ray was pending)
 {
     float sum = L.x + L.y + L.z;
-    if (!(sum - sum == 0.0f)) { L = V1(0.0f); if (STATS) lc[9] += 1; }
+    if (!(sum - sum == 0.0f)) {
+        L = V1(0.0f);
+        if (STATS) { // counting launches also note WHERE (the first HJR_NAN_LIST of them, in no particular order): x | y << 13 | sample << 26
+            lc[9] += 1;
+            const unsigned long long slot = atomicAdd(&P.nan_list[0], 1ull);
+            if (slot < HJR_NAN_LIST) P.nan_list[1 + slot] = (unsigned long long)HJR_PX(c) | ((unsigned long long)HJR_PY(c) << 13) | ((unsigned long long)(c.s - s_back) << 26);
+        }
+    }
     c.sumL = c.sumL + L;
     if (STATS) lc[0] += 1;
 }
@@ -295,7 +302,7 @@ template <bool AOVS> HD void write_out(const KParams& P, LaneCtx& c)
 {
     const float inv_spp = 1.0f / (float)P.spp;
     // AOV element of the pixel: row-major frame, or (HJR_FLAG_PACKED) this rank's tiles back to back: (owned tile index) * 64 + pixel in tile
-    const size_t pix = P.packed ? (size_t)(((HJR_PY(c) / HJR_TILE) * P.tiles_x + HJR_PX(c) / HJR_TILE) / P.world) * 64u + ((HJR_PY(c) & 7u) * 8u + (HJR_PX(c) & 7u))
+    const size_t pix = P.packed ? (size_t)(hjr_tile_id(HJR_PX(c) / HJR_TILE, HJR_PY(c) / HJR_TILE, P.tiles_x) / P.world) * 64u + ((HJR_PY(c) & 7u) * 8u + (HJR_PX(c) & 7u))
                                 : (size_t)HJR_PX(c) + (size_t)HJR_PY(c) * P.width;
     f3 sumA = c.sumA, sumN = c.sumN;
     if (AOVS && c.aov) { const float4 a = c.aov[0], n = c.aov[1]; sumA = V(a.x, a.y, a.z); sumN = V(n.x, n.y, n.z); }
@@ -305,7 +312,7 @@ template <bool AOVS> HD void write_out(const KParams& P, LaneCtx& c)
         if (AOVS && P.aov_normal) P.aov_normal[pix] = make_float4(sumN.x * inv_spp, sumN.y * inv_spp, sumN.z * inv_spp, 1.0f);
     } else { // chunk sum -> HBM; hjr_finalize_kernel adds the chunks of a pixel in chunk order.  The buffers hold this rank's
              // tiles only: slot = ((chunk * owned tiles) + owned tile index) * 64 + pixel in tile
-        const uint32_t otile = ((HJR_PY(c) / HJR_TILE) * P.tiles_x + HJR_PX(c) / HJR_TILE) / P.world;
+        const uint32_t otile = hjr_tile_id(HJR_PX(c) / HJR_TILE, HJR_PY(c) / HJR_TILE, P.tiles_x) / P.world;
         const size_t slot = ((size_t)HJR_CHUNK(c) * P.n_owned_tiles + otile) * 64u + ((HJR_PY(c) & 7u) * 8u + (HJR_PX(c) & 7u));
         P.part_color[slot] = make_float4(c.sumL.x, c.sumL.y, c.sumL.z, 0.0f);
         if (AOVS && P.part_albedo) P.part_albedo[slot] = make_float4(sumA.x, sumA.y, sumA.z, 0.0f);
@@ -334,7 +341,7 @@ HD void bounce_pre_trace(const KParams& P, LaneCtx& c, WaveRange& wr, const bool
             if (russian_p < xi_rr) {
                 if (c.sh_valid) { c.fin_pending = true; close_sample(P, c); } // radiance final once the pending shadow ray is resolved
                 else { // nothing pending: the sample is final now, and if it was the item's last one the lane refills below
-                    finish_sample<STATS>(c, c.ps.L, lc);
+                    finish_sample<STATS>(P, c, c.ps.L, lc);
                     c.ps.L = V1(0.0f);
                     close_sample(P, c);
                     if (!ONEWRITE && c.write_pending) write_out<AOVS>(P, c);
@@ -390,7 +397,7 @@ HD void bounce_pre_trace(const KParams& P, LaneCtx& c, WaveRange& wr, const bool
             // measured cost of a tile (orders the tiles of the next frame, hjr_cost_hist_kernel): a lane sums the rays of its
             // consecutive items of one tile and flushes when it moves on; lanes leaving the same tile together (the usual
             // case) share one atomic.  All lanes are here (m is wave-uniform), so the shuffles below are well defined.
-            const uint32_t old_tile = (HJR_PY(c) / HJR_TILE) * P.tiles_x + HJR_PX(c) / HJR_TILE;
+            const uint32_t old_tile = hjr_tile_id(HJR_PX(c) / HJR_TILE, HJR_PY(c) / HJR_TILE, P.tiles_x);
             uint32_t new_tile = 0xffffffffu;
             if (need && q < P.n_owned_items) new_tile = P.tile_order ? P.tile_order[(q >> 6) / P.n_chunks] : ((q >> 6) / P.n_chunks) * P.world + P.rank;
             bool flush = need && P.tile_cost && c.it_cost != 0u && new_tile != old_tile;
@@ -410,7 +417,8 @@ HD void bounce_pre_trace(const KParams& P, LaneCtx& c, WaveRange& wr, const bool
                     const uint32_t tc = q >> 6;
                     const uint32_t tile = new_tile;
                     const uint32_t chunk = tc % P.n_chunks;
-                    const uint32_t tx = tile % P.tiles_x, ty = tile / P.tiles_x;
+                    uint32_t tx, ty;
+                    hjr_tile_xy(tile, P.tiles_x, &tx, &ty);
                     const uint32_t px = tx * HJR_TILE + (q & 7u);
                     const uint32_t py = ty * HJR_TILE + ((q >> 3) & 7u);
                     if (px < P.width && py < P.height) {
@@ -452,7 +460,7 @@ HD void bounce_post_trace(const KParams& P, const float4* nodes, const float4* t
         if (INTEGRATOR == HJR_INTEGRATOR_MIS_) { ps.L = ps.L + c.mis_contrib; c.mis_contrib = V1(0.0f); } // rt.h:378 first, then :414 / :418
     }
     if (c.fin_pending) {
-        finish_sample<STATS>(c, ps.L, lc);
+        finish_sample<STATS>(P, c, ps.L, lc, 1u);
         ps.L = V1(0.0f); // from here on ps.L belongs to the path that was regenerated (or to nothing)
         c.fin_pending = false;
         if (!ONEWRITE && c.write_pending) write_out<AOVS>(P, c);
@@ -473,7 +481,7 @@ HD void bounce_post_trace(const KParams& P, const float4* nodes, const float4* t
     if (!prd.is_hit || prd.is_light) {
         // NEE / MIS count emission only at depth 0 (rt.h:196-208, 318-330); Pathtrace always (rt.h:118-126)
         if (INTEGRATOR == HJR_INTEGRATOR_PT_ || ps.depth == 0) ps.L = ps.L + ps.thr * prd.emission;
-        finish_sample<STATS>(c, ps.L, lc);
+        finish_sample<STATS>(P, c, ps.L, lc);
         close_sample(P, c);
         if (!ONEWRITE && c.write_pending) write_out<AOVS>(P, c);
         return;
@@ -585,7 +593,7 @@ HD void bounce_post_trace(const KParams& P, const float4* nodes, const float4* t
     if (ps.depth == 10) { // MaxDepth (rt.h:166): the path is over; its last shadow ray, if any, is still pending
         if (c.sh_valid) { c.fin_pending = true; close_sample(P, c); }
         else {
-            finish_sample<STATS>(c, ps.L, lc);
+            finish_sample<STATS>(P, c, ps.L, lc);
             ps.L = V1(0.0f);
             close_sample(P, c);
             if (!ONEWRITE && c.write_pending) write_out<AOVS>(P, c);
@@ -619,7 +627,7 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
 {
     constexpr bool AOVS = VAR >= 1, TEX = VAR == 2;
     typedef typename std::conditional<STACK16, uint16_t, uint32_t>::type SE; // stack entry type
-    typedef LaneStack<SE, BLOCK, !LDSBVH, STATS> ST;
+    typedef LaneStack<SE, BLOCK, !LDSBVH, STATS, LDSBVH> ST;
     ST stack;
     stack.n_over = 0;
     stack.lds = reinterpret_cast<SE*>(hjr_smem) + threadIdx.x;
@@ -646,6 +654,7 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
 #ifdef HJR_TIMING
     // diagnostic build: wave-clock shares of the loop's phases, summed per wave into P.stats[HJR_NSTAT..] (never in the shipped build)
     unsigned long long tk[3] = { 0, 0, 0 }, oc[4] = { 0, 0, 0, 0 }; // rounds, lanes tracing closest, lanes with a shadow ray, lanes serviced
+    unsigned long long td[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }; // traversal lane occupancy (hjr_traverse.hip.h): per-lane sums, added up at the end
     unsigned long long tstamp = __builtin_amdgcn_s_memtime();
 #define HJR_TICK(i) { __builtin_amdgcn_sched_barrier(0); unsigned long long now_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); tk[i] += now_ - tstamp; tstamp = now_; }
 #else
@@ -665,7 +674,11 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
         {
             Counters ca, cb; ca.box = ca.tri = cb.box = cb.tri = 0;
             const f3 cam_o = V(P.cam_pos[0], P.cam_pos[1], P.cam_pos[2]);
-            inflight = traverse_fused<STATS, WIDTH, BLOCK, ST, (LDSBVH ? HJR_CARRY_LDS : HJR_CARRY_MEM)>(nodes, tris, c.sh_valid, c.ps.ro, c.sh_d, c.sh_tmax, tracing, c.fresh ? cam_o : c.ps.ro, c.ps.rd, occluded, h, stack, ca, cb, inflight || (HOLD && hold != 0u), tc, P.node_min);
+            inflight = traverse_fused<STATS, WIDTH, BLOCK, ST, (LDSBVH ? HJR_CARRY_LDS : HJR_CARRY_MEM)>(nodes, tris, c.sh_valid, c.ps.ro, c.sh_d, c.sh_tmax, tracing, c.fresh ? cam_o : c.ps.ro, c.ps.rd, occluded, h, stack, ca, cb, inflight || (HOLD && hold != 0u), tc, P.node_min
+#ifdef HJR_TIMING
+                                                                                                                   , td
+#endif
+            );
             if (STATS) { // tests are counted round by round, rays when they are resolved
                 lc[5] += ca.box; lc[6] += ca.tri; lc[3] += cb.box; lc[4] += cb.tri;
                 if (!inflight && (!HOLD || hold == 0u)) { if (c.sh_valid) lc[2] += 1; if (tracing) lc[1] += 1; }
@@ -704,6 +717,11 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
 #ifdef HJR_TIMING
     if (lane == 0) for (int i = 0; i < 3; i++) atomicAdd(&P.stats[HJR_NSTAT + i], tk[i]);
     if (__ffsll((long long)__ballot(true)) - 1 == (int)lane) for (int i = 0; i < 4; i++) atomicAdd(&P.stats[HJR_NSTAT + 3 + i], oc[i]);
+    for (int i = 0; i < 10; i++) {
+        unsigned long long v = td[i];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+        if (lane == 0 && v) atomicAdd(&P.stats[HJR_NSTAT + 7 + i], v);
+    }
 #endif
 
     if (STATS) {

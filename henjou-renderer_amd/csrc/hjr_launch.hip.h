@@ -200,6 +200,11 @@ template <int I, bool S> int hjr_launch(hjr_ctx* c, const KParams& kp_in, uint64
     if (const char* e = getenv("HJR_HOLD_MIN")) { int v = atoi(e); if (v >= 0 && v <= 64) kp.hold_min = (uint32_t)v; } // tuning knobs
     if (const char* e = getenv("HJR_HOLD_AGE")) { int v = atoi(e); if (v >= 1 && v <= 1000) kp.hold_age = (uint32_t)v; }
     kp.node_min = nm_forced ? nm_forced : (lds_layout ? (wf ? HJR_NODE_MIN_LDS_WF : HJR_NODE_MIN_LDS) : HJR_NODE_MIN_MEM);
+#ifdef HJR_LEAN_VARIANT /* kernel experiments (make variant X="-DHJR_LEAN_VARIANT ..."): only the LDS-resident megakernel is instantiated: builds in seconds */
+    c->stats.pipeline = 0u;
+    if (!nm_forced) kp.node_min = HJR_NODE_MIN_LDS;
+    return lds_mode == 1 ? launch_lds<I, S, false>(c, kp, n_items, st) : -1;
+#else
     if (wf) {
         const int rc = launch_wf<I, S>(c, kp, n_items, lds_mode, st);
         if (rc != -2) return rc;
@@ -210,6 +215,7 @@ template <int I, bool S> int hjr_launch(hjr_ctx* c, const KParams& kp_in, uint64
     if (lds_mode == 2) return launch_lds<I, S, true>(c, kp, n_items, st);
     if (lds_mode == 3) return launch_mem<I, S, 2>(c, kp, n_items, st); // BVH2 read from memory (HJR_BVH_WIDTH=2 knob on a big scene)
     return launch_mem<I, S, 4>(c, kp, n_items, st);
+#endif
 }
 template <int I, bool S, int W> static int launch_mem(hjr_ctx* c, const KParams& kp, uint64_t n_items, hipStream_t st)
 {

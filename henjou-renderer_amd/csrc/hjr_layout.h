@@ -4,6 +4,22 @@
 #include <stdint.h>
 
 #define HJR_TILE 8u                 /* 8x8 pixel tiles = one wavefront of pixels */
+/* Tile ids of the pixel-tile shard.  Tile (tx, ty) has id  t = ty * tiles_x + (tx + ty) % tiles_x : rows of tiles, row ty rotated by ty
+ * places.  Tile t belongs to rank t % world and is that rank's (t / world)-th tile.  Without the rotation a frame whose tiles_x is a
+ * multiple of the GPU count (1080p: 240, 4K: 480; 2, 4, 8 GPUs) would give every rank a fixed set of 8-pixel vertical stripes; with it
+ * a rank's tiles run along diagonals, whatever tiles_x is.  Per-rank tile counts are unchanged (each row is a permutation of itself). */
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#define HJR_LAYOUT_FN __host__ __device__ static inline
+#else
+#define HJR_LAYOUT_FN static inline
+#endif
+HJR_LAYOUT_FN uint32_t hjr_tile_id(uint32_t tx, uint32_t ty, uint32_t tiles_x) { return ty * tiles_x + (tx + ty) % tiles_x; }
+HJR_LAYOUT_FN void hjr_tile_xy(uint32_t t, uint32_t tiles_x, uint32_t* tx, uint32_t* ty)
+{
+    const uint32_t y = t / tiles_x, c = t - y * tiles_x, r = y % tiles_x;
+    *ty = y;
+    *tx = c >= r ? c - r : c + tiles_x - r;
+}
 #define HJR_STACK_DEPTH 32          /* per-lane traversal stack entries (LDS); the builder caps tree depth at this */
 #define HJR_LEAF_FLAG 0x80000000u   /* child ref: bit31 = leaf, bits 27..30 = triangle count, bits 0..26 = first triangle */
 #define HJR_LEAF_MAX 4u              /* encoding cap */
@@ -17,9 +33,11 @@
  * Measured on MI355X (profiles/r01_experiments.md): cornelbox in LDS 223 ms (BVH2) vs 249 ms (BVH4); 1 M-triangle stress scene
  * from memory 643 ms (BVH2) vs 501 ms (BVH4).
  *
- * BVH2 node, 64 B = 4 x float4; holds the (padded) boxes of both children.
- *   q0 = (lo0.x lo0.y lo0.z hi0.x)  q1 = (hi0.y hi0.z lo1.x lo1.y)  q2 = (lo1.z hi1.x hi1.y hi1.z)
- *   q3 = (child0, child1, 0, 0) as uint bits
+ * BVH2 node, 64 B = 4 x float4; holds the (padded) boxes of both children, one row per axis with the children side by side:
+ *   q0 = (lo0.x lo1.x hi0.x hi1.x)  q1 = (lo0.y lo1.y hi0.y hi1.y)  q2 = (lo0.z lo1.z hi0.z hi1.z)
+ *   q3 = (child0, child1, child0, child1) as uint bits
+ *   A ray reads the near pair and the far pair of each axis (8 bytes each) at an offset picked by the sign of its direction,
+ *   so the slab test of both children is 6 packed fmas + max3 / min3, no per-axis min / max (hjr_traverse.hip.h::node_step).
  * BVH4 node, 112 B = 7 x float4, child-major planes so that one 16-byte read yields the same plane of all four children:
  *   q0 = lo.x[0..3]  q1 = hi.x[0..3]  q2 = lo.y[0..3]  q3 = hi.y[0..3]  q4 = lo.z[0..3]  q5 = hi.z[0..3]  q6 = child refs[0..3]
  *   A ray picks its near/far plane rows by the sign of its direction, so the slab test needs no min/max.
@@ -46,6 +64,7 @@
  *   pdf = float(1.0 / area) * (1.0f / light_prim_count) */
 #define HJR_LIGHT_F4 6
 
+#define HJR_NAN_LIST 8 /* NaN / Inf samples a counting launch locates (hjr_stats.nan_where) */
 #define HJR_NSTAT 11 /* hjr_stats' ten leading uint64 counters in order, then [10] = stack_overflow_pushes */
 
 /* Work-item chunking: a pixel's spp samples are cut into n_chunks runs of chunk_spp consecutive samples

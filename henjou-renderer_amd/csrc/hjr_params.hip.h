@@ -23,6 +23,7 @@ struct KParams {
     float4* aov_normal;
     unsigned int* queue_head;
     unsigned long long* stats;
+    unsigned long long* nan_list;    // counting launches: [0] NaN / Inf samples seen, [1 ..] the first HJR_NAN_LIST of them as x | y << 13 | sample << 26
     int lut_w, lut_h;
     int sky_w, sky_h;
     uint32_t n_lights;

@@ -13,7 +13,8 @@ HD f3 crossf(f3 a, f3 b)
 {
     return V(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
 }
-// canonical ray/triangle test — the same operation sequence as the oracle's ray_tri()
+// canonical ray/triangle test — the same operation sequence as the oracle's ray_tri().  The early returns stay: a
+// version without them (all seven conditions combined at the end) ran 2.5 % slower on the bundled scene (profiles/r03_experiments.md).
 HD bool ray_tri(f3 v0, f3 v1, f3 v2, f3 o, f3 d, float tmin, float tmax, float& t, float& b1, float& b2)
 {
     f3 e1 = v1 - v0, e2 = v2 - v0;
@@ -64,8 +65,9 @@ HDH uint32_t stack_dec(uint16_t r16)
 #ifndef HJR_SHORT_STACK
 #define HJR_SHORT_STACK 16
 #endif
-template <typename E, int BLOCK_, bool SPILL, bool COUNT = false>
+template <typename E, int BLOCK_, bool SPILL, bool COUNT = false, bool NLDS = false>
 struct LaneStack {
+    static constexpr bool kNodesInLds = NLDS; // the kernel stages nodes (and triangles) in LDS: node addresses are 32-bit LDS addresses
     E* lds;
     uint32_t* spill;
     uint32_t spill_stride;
@@ -97,47 +99,74 @@ struct LaneStack {
 // ---- box-test side of a ray.  The slab test only has to be conservative (boxes are padded): it uses the
 // 1-ulp hardware reciprocal and (plane - o) * inv evaluated as fma(plane, inv, -o * inv).  Direction components smaller than
 // 1e-30 are clamped (sign kept) so that inv stays finite and no inf - inf can appear for axis-parallel rays.
-struct BoxRay {
-    f3 inv, oi;
-    uint32_t sx, sy, sz; // BVH4 only: 1 when the direction component is negative (near plane row = hi)
-};
+typedef float v2f __attribute__((ext_vector_type(2))); // 8-byte loads of a plane pair
+typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const char lds_cchar;
 HD float box_dir(float d) { return (fabsf(d) < 1e-30f) ? copysignf(1e-30f, d) : d; }
-HD BoxRay box_ray(f3 o, f3 d)
+// BVH4 (nodes always read from memory): reciprocal direction, -o * inv, and the near-row selectors (1: the component is negative)
+// BVH2: the same six floats, and per axis the address of the ray's near-plane pair in node 0 — node base + the byte offset the
+// direction's sign selects (hjr_layout.h) — as a 32-bit LDS address when the nodes are staged in LDS (NLDS).
+template <int WIDTH, bool NLDS> struct BoxRay {
+    f3 inv, oi;
+    uint32_t sx, sy, sz;
+};
+template <bool NLDS> struct BoxRay<2, NLDS> {
+    f3 inv, oi;
+    typename std::conditional<NLDS, uint32_t, const char*>::type ax, ay, az;
+};
+template <int WIDTH, bool NLDS> HD BoxRay<WIDTH, NLDS> box_ray(const float4* nodes, f3 o, f3 d)
 {
-    BoxRay r;
+    BoxRay<WIDTH, NLDS> r;
     const f3 dd = V(box_dir(d.x), box_dir(d.y), box_dir(d.z));
-    r.inv = V(__builtin_amdgcn_rcpf(dd.x), __builtin_amdgcn_rcpf(dd.y), __builtin_amdgcn_rcpf(dd.z));
-    r.oi = V(-o.x * r.inv.x, -o.y * r.inv.y, -o.z * r.inv.z);
-    r.sx = dd.x < 0.0f ? 1u : 0u; r.sy = dd.y < 0.0f ? 1u : 0u; r.sz = dd.z < 0.0f ? 1u : 0u; // dead code in the BVH2 kernels
+    const f3 inv = V(__builtin_amdgcn_rcpf(dd.x), __builtin_amdgcn_rcpf(dd.y), __builtin_amdgcn_rcpf(dd.z));
+    const f3 oi = V(-o.x * inv.x, -o.y * inv.y, -o.z * inv.z);
+    if constexpr (WIDTH == 2) {
+        r.inv = inv; r.oi = oi;
+        const uint32_t kx = dd.x < 0.0f ? 8u : 0u, ky = dd.y < 0.0f ? 24u : 16u, kz = dd.z < 0.0f ? 40u : 32u;
+        if constexpr (NLDS) {
+            const uint32_t base = (uint32_t)reinterpret_cast<uintptr_t>((lds_cchar*)reinterpret_cast<const char*>(nodes));
+            r.ax = base + kx; r.ay = base + ky; r.az = base + kz;
+        } else {
+            const char* base = reinterpret_cast<const char*>(nodes);
+            r.ax = base + kx; r.ay = base + ky; r.az = base + kz;
+        }
+    } else {
+        r.inv = inv; r.oi = oi;
+        r.sx = dd.x < 0.0f ? 1u : 0u; r.sy = dd.y < 0.0f ? 1u : 0u; r.sz = dd.z < 0.0f ? 1u : 0u;
+    }
     return r;
 }
+// the 8-byte plane pair / child pair at byte address a (+ an immediate)
+template <typename T> HD T node_ld(uint32_t a, uint32_t imm) { return *reinterpret_cast<__attribute__((address_space(3))) const T*>((uintptr_t)(a + imm)); }
+template <typename T> HD T node_ld(const char* a, uint32_t imm) { return *reinterpret_cast<const T*>(a + imm); }
+HD uint32_t node_far(uint32_t a) { return a ^ 8u; }
+HD const char* node_far(const char* a) { return reinterpret_cast<const char*>(reinterpret_cast<uintptr_t>(a) ^ (uintptr_t)8); }
 
 #define HJR_TRAV_DONE 0xffffffffu
 // One inner-node step: tests the children of node `cur` against [tmin, tfar], continues with the nearest hit child, pushes
 // the other hit children, or pops (HJR_TRAV_DONE when the stack is empty).  Returns the number of boxes tested.
 template <int WIDTH, int BLOCK, typename ST>
-HD uint32_t node_step(const float4* nodes, uint32_t& cur, const BoxRay& R, float tmin, float tfar, ST& stack, int& sp)
+HD uint32_t node_step(const float4* nodes, uint32_t& cur, const BoxRay<WIDTH, ST::kNodesInLds>& R, float tmin, float tfar, ST& stack, int& sp)
 {
     if constexpr (WIDTH == 2) {
-    const float4* nd = nodes + cur * HJR_NODE2_F4;
-    const float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
+    // A ray reads the near and the far plane pair of each axis straight from the node (rows of (lo0 lo1 hi0 hi1), the pair picked by
+    // the sign of the direction: an address, not a min / max) and folds the three axes with max3 / min3: 7 address + 12 fma + 8 min /
+    // max instructions, against 12 fma + 18 min / max for the lo / hi box layout of rounds 1 - 2 (bundled scene: 125.7 -> 122.4 ms).
+    // Nodes are 64-byte aligned, so the far pair of an axis is at (near address ^ 8).  One v_pk_fma_f32 per pair instead of two
+    // v_fma_f32 was measured 2.5 % SLOWER (packed fp32 fma does not issue at the scalar rate here; profiles/r03_experiments.md).
+    const uint32_t nofs = cur * (uint32_t)(HJR_NODE2_F4 * 16);
+    const auto anx = R.ax + nofs, any = R.ay + nofs, anz = R.az + nofs;
+    const v2f nx = node_ld<v2f>(anx, 0), fx = node_ld<v2f>(node_far(anx), 0);
+    const v2f ny = node_ld<v2f>(any, 0), fy = node_ld<v2f>(node_far(any), 0);
+    const v2f nz = node_ld<v2f>(anz, 0), fz = node_ld<v2f>(node_far(anz), 0);
+    const v2u cc = node_ld<v2u>(anx, 48); // the child refs are stored twice (bytes 48 and 56): one immediate offset from the near-x address
     const f3 inv = R.inv, oi = R.oi;
-    float t0 = fmaf(q0.x, inv.x, oi.x), t1 = fmaf(q0.w, inv.x, oi.x);
-    float lo0 = fminf(t0, t1), hi0 = fmaxf(t0, t1);
-    t0 = fmaf(q0.y, inv.y, oi.y); t1 = fmaf(q1.x, inv.y, oi.y);
-    lo0 = fmaxf(lo0, fminf(t0, t1)); hi0 = fminf(hi0, fmaxf(t0, t1));
-    t0 = fmaf(q0.z, inv.z, oi.z); t1 = fmaf(q1.y, inv.z, oi.z);
-    lo0 = fmaxf(lo0, fminf(t0, t1)); hi0 = fminf(hi0, fmaxf(t0, t1));
-    lo0 = fmaxf(lo0, tmin); hi0 = fminf(hi0, tfar);
-    t0 = fmaf(q1.z, inv.x, oi.x); t1 = fmaf(q2.y, inv.x, oi.x);
-    float lo1 = fminf(t0, t1), hi1 = fmaxf(t0, t1);
-    t0 = fmaf(q1.w, inv.y, oi.y); t1 = fmaf(q2.z, inv.y, oi.y);
-    lo1 = fmaxf(lo1, fminf(t0, t1)); hi1 = fminf(hi1, fmaxf(t0, t1));
-    t0 = fmaf(q2.x, inv.z, oi.z); t1 = fmaf(q2.w, inv.z, oi.z);
-    lo1 = fmaxf(lo1, fminf(t0, t1)); hi1 = fminf(hi1, fmaxf(t0, t1));
-    lo1 = fmaxf(lo1, tmin); hi1 = fminf(hi1, tfar);
+    const float lo0 = fmaxf(fmaxf(fmaf(nx.x, inv.x, oi.x), fmaf(ny.x, inv.y, oi.y)), fmaxf(fmaf(nz.x, inv.z, oi.z), tmin));
+    const float hi0 = fminf(fminf(fmaf(fx.x, inv.x, oi.x), fmaf(fy.x, inv.y, oi.y)), fminf(fmaf(fz.x, inv.z, oi.z), tfar));
+    const float lo1 = fmaxf(fmaxf(fmaf(nx.y, inv.x, oi.x), fmaf(ny.y, inv.y, oi.y)), fmaxf(fmaf(nz.y, inv.z, oi.z), tmin));
+    const float hi1 = fminf(fminf(fmaf(fx.y, inv.x, oi.x), fmaf(fy.y, inv.y, oi.y)), fminf(fmaf(fz.y, inv.z, oi.z), tfar));
     const bool h0 = lo0 <= hi0, h1 = lo1 <= hi1; // conservative through the 2^-15 box padding (>= 16x the rounding error of t)
-    const uint32_t c0 = f2bits(q3.x), c1 = f2bits(q3.y);
+    const uint32_t c0 = cc.x, c1 = cc.y;
     if (h0 && h1) {
         const bool swap = lo1 < lo0;
         stack.put(sp, swap ? c0 : c1);
@@ -185,7 +214,7 @@ struct Hit { float t, b1, b2; uint32_t k, prim; };
 template <bool ANY, bool STATS, int WIDTH, int BLOCK, typename ST>
 HD bool traverse(const float4* nodes, const float4* tris, f3 o, f3 d, float tmin, float tmax, Hit& hit, ST& stack, Counters& cnt)
 {
-    const BoxRay R = box_ray(o, d);
+    BoxRay<WIDTH, ST::kNodesInLds> R = box_ray<WIDTH, ST::kNodesInLds>(nodes, o, d);
     int sp = 0;
     uint32_t cur = 0;
     hit.prim = 0xffffffffu;
@@ -246,8 +275,16 @@ HD bool traverse(const float4* nodes, const float4* tris, f3 o, f3 d, float tmin
 struct TravCarry { uint32_t cur; int sp, phase; };
 template <bool STATS, int WIDTH, int BLOCK, typename ST, int CARRY>
 HD bool traverse_fused(const float4* nodes, const float4* tris, const bool a_valid, const f3 ao, const f3 ad, const float a_tmax, const bool b_valid,
-                       const f3 bo, const f3 bd, bool& occluded, Hit& hit, ST& stack, Counters& ca, Counters& cb, const bool resume, TravCarry& tc, const uint32_t node_min)
+                       const f3 bo, const f3 bd, bool& occluded, Hit& hit, ST& stack, Counters& ca, Counters& cb, const bool resume, TravCarry& tc, const uint32_t node_min,
+                       unsigned long long* td = nullptr)
 {
+#ifdef HJR_TIMING /* diagnostic build: lane occupancy of the loop's parts.  A wave-level event is counted by the first active lane, lane sums by every lane */
+#define HJR_TD_WAVE(i) { if (__ffsll((long long)__ballot(true)) - 1 == (int)(threadIdx.x & 63u)) td[i] += 1; }
+#define HJR_TD_LANE(i) { td[i] += 1; }
+#else
+#define HJR_TD_WAVE(i) {}
+#define HJR_TD_LANE(i) {}
+#endif
     const float tmin = 0.001f;
     int phase, sp;
     uint32_t cur;
@@ -255,38 +292,49 @@ HD bool traverse_fused(const float4* nodes, const float4* tris, const bool a_val
     else {
         occluded = false;
         hit.prim = 0xffffffffu;
-        hit.t = 1e16f;
+        hit.t = a_valid ? a_tmax : 1e16f; // hit.t is the far end of the ray being traced: the shadow ray's tmax in phase 0, the closest hit so far in phase 1
         phase = a_valid ? 0 : (b_valid ? 1 : 2);
         sp = 0;
         cur = (phase < 2) ? 0u : HJR_TRAV_DONE;
     }
     f3 o = (phase == 0) ? ao : bo;
     f3 d = (phase == 0) ? ad : bd;
-    BoxRay R = box_ray(o, d);
+    BoxRay<WIDTH, ST::kNodesInLds> R = box_ray<WIDTH, ST::kNodesInLds>(nodes, o, d);
     const int n_start = CARRY > 0 ? __popcll(__ballot(phase < 2)) : 0;
     for (;;) {
         if (CARRY > 0) {
             const int n_act = __popcll(__ballot(phase < 2));
             if (n_act == 0 || (n_act <= CARRY && n_act < n_start)) break;
         } else if (__ballot(phase < 2) == 0ull) break;
+        HJR_TD_WAVE(0)
         if (phase < 2) {
+        HJR_TD_LANE(1)
+        if (phase == 0) { HJR_TD_LANE(8) }
         // "while-while" traversal: every lane first descends through inner nodes until it holds a leaf (or is out of work), or until
         // fewer than node_min lanes are still descending (they go on in the next pass) ...
         for (;;) {
+            HJR_TD_WAVE(2)
             if (!(cur & HJR_LEAF_FLAG)) {
-                const float tfar = (phase == 0) ? a_tmax : hit.t;
-                const uint32_t nb = node_step<WIDTH, BLOCK, ST>(nodes, cur, R, tmin, tfar, stack, sp);
+                HJR_TD_LANE(3)
+                const uint32_t nb = node_step<WIDTH, BLOCK, ST>(nodes, cur, R, tmin, hit.t, stack, sp);
                 if (STATS) { if (phase == 0) ca.box += nb; else cb.box += nb; }
             }
             const uint32_t n_inner = (uint32_t)__popcll(__ballot(!(cur & HJR_LEAF_FLAG)));
             if (n_inner == 0u || n_inner < node_min) break;
+#ifdef HJR_EXP_GREEDY /* experiment: leave the descent as soon as the lanes holding a leaf outnumber (x HJR_EXP_GREEDY / 4) those still descending */
+            if (n_inner * 4u < (uint32_t)__popcll(__ballot((cur & HJR_LEAF_FLAG) && cur != HJR_TRAV_DONE)) * (uint32_t)(HJR_EXP_GREEDY)) break;
+#endif
         }
         // ... then all lanes that hold a leaf test its triangles together
         bool done = (cur == HJR_TRAV_DONE);
         if (!done && (cur & HJR_LEAF_FLAG)) {
+            HJR_TD_WAVE(4)
+            HJR_TD_LANE(5)
             const uint32_t first = cur & 0x07ffffffu, count = (cur >> 27) & 15u;
             const float tri_tmax = (phase == 0) ? a_tmax : 1e16f;
             for (uint32_t i = 0; i < count; i++) {
+                HJR_TD_WAVE(6)
+                HJR_TD_LANE(7)
                 const float4* g = tris + (first + i) * HJR_TRI_F4;
                 const float4 g0 = g[0], g1 = g[1], g2 = g[2];
                 float t, b1, b2;
@@ -308,8 +356,9 @@ HD bool traverse_fused(const float4* nodes, const float4* tris, const bool a_val
         if (done) {
             if (phase == 0 && b_valid) { // this lane's shadow ray is resolved: start its closest-hit ray right away
                 phase = 1;
+                hit.t = 1e16f;
                 o = bo; d = bd;
-                R = box_ray(o, d);
+                R = box_ray<WIDTH, ST::kNodesInLds>(nodes, o, d);
                 sp = 0; cur = 0;
             } else { phase = 2; cur = HJR_TRAV_DONE; }
         }

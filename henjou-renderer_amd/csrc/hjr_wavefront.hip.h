@@ -271,7 +271,7 @@ HD void wf_trace_stage(const KParams& P, WfShared* Q, wf_ring_ptr rings, const f
     float a_tmax = 0.0f;
     bool b_valid = false, fresh = false, occluded = false;
     Hit hit; hit.prim = 0xffffffffu; hit.t = 1e16f; hit.k = 0; hit.b1 = hit.b2 = 0.0f;
-    BoxRay R = box_ray(o, d);
+    BoxRay<WIDTH, ST::kNodesInLds> R = box_ray<WIDTH, ST::kNodesInLds>(nodes, o, d);
     bool n_valid = false; // prefetched context
     uint32_t n_id = 0;
     float4 n0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), n1 = n0, n2 = n0;
@@ -304,7 +304,7 @@ HD void wf_trace_stage(const KParams& P, WfShared* Q, wf_ring_ptr rings, const f
             phase = (flags & WF_SH_VALID) ? 0 : 1; // a queued context has at least one of the two rays
             o = (phase == 0 || !fresh) ? ro : cam_o;
             d = (phase == 0) ? V(n2.x, n2.y, n2.z) : db;
-            R = box_ray(o, d);
+            R = box_ray<WIDTH, ST::kNodesInLds>(nodes, o, d);
             sp = 0; cur = 0;
             n_valid = false;
         }
@@ -371,7 +371,7 @@ HD void wf_trace_stage(const KParams& P, WfShared* Q, wf_ring_ptr rings, const f
                 if (phase == 0 && b_valid) { // this lane's shadow ray is resolved: start its closest-hit ray right away
                     phase = 1;
                     o = fresh ? cam_o : ro; d = db;
-                    R = box_ray(o, d);
+                    R = box_ray<WIDTH, ST::kNodesInLds>(nodes, o, d);
                     sp = 0; cur = 0;
                 } else finish();
             }
@@ -434,7 +434,7 @@ __global__ void __launch_bounds__(BLOCK, 1) hjr_wavefront_kernel(const KParams P
 {
     constexpr bool AOVS = VAR >= 1, TEX = VAR == 2; // as in hjr_render_kernel
     typedef uint32_t SE;
-    typedef LaneStack<SE, BLOCK, SPILL, STATS> ST;
+    typedef LaneStack<SE, BLOCK, SPILL, STATS, LDSBVH> ST;
     ST stack;
     stack.n_over = 0;
     stack.lds = reinterpret_cast<SE*>(hjr_smem) + threadIdx.x;

@@ -11,6 +11,8 @@
 #include <vector>
 
 #include "../../include/henjou_hip.h"
+#include "../csrc/hjr_layout.h"
+#include "abi.hpp"
 #include "scene.hpp"
 
 namespace hjr {
@@ -35,25 +37,33 @@ extern "C" const char* hjr_last_error(void) { return hjr::g_err.c_str(); }
 extern "C" int hjr_load_render_option(const char* json_path, hjr_render_option* out)
 {
     if (!json_path || !out) { set_error("hjr_load_render_option: null argument"); return HJR_ERR_ARG; }
+    uint32_t out_size;
+    if (!hjr::abi_size(out, out_size, "hjr_load_render_option")) return HJR_ERR_ARG;
     std::string err;
-    if (!hjr::load_render_option(json_path, *out, err)) {
+    hjr_render_option opt;
+    if (!hjr::load_render_option(json_path, opt, err)) {
         set_error(err);
         return err.rfind("File ", 0) == 0 ? HJR_ERR_IO : HJR_ERR_PARSE;
     }
-    return HJR_OK;
+    opt.struct_size = (uint32_t)sizeof(opt);
+    return hjr::abi_give(out, opt, "hjr_load_render_option") ? HJR_OK : HJR_ERR_ARG; // sized struct: at most out->struct_size bytes are written
 }
 
 extern "C" int hjr_scene_load_gltf(const char* dir, const char* file, hjr_render_option* opt, hjr_scene** out)
 {
     if (!dir || !file || !opt || !out) { set_error("hjr_scene_load_gltf: null argument"); return HJR_ERR_ARG; }
     *out = nullptr;
+    hjr_render_option o; // sized struct, in / out: the loader may enable the camera animation (gltfloader.h:1296-1310)
+    if (!hjr::abi_take(opt, o, "hjr_scene_load_gltf")) return HJR_ERR_ARG;
+    const std::string dir_s = dir, file_s = file; // (dir / file usually point into *opt)
     hjr_scene* s = new hjr_scene();
     std::string err;
-    if (!hjr::load_gltf(dir, file, s->data, *opt, err)) {
+    if (!hjr::load_gltf(dir_s, file_s, s->data, o, err)) {
         set_error(err);
         delete s;
         return err.find("cannot open") != std::string::npos ? HJR_ERR_IO : HJR_ERR_PARSE;
     }
+    if (!hjr::abi_give(opt, o, "hjr_scene_load_gltf")) { delete s; return HJR_ERR_ARG; }
     *out = s;
     return HJR_OK;
 }
@@ -63,8 +73,12 @@ extern "C" void hjr_scene_free(hjr_scene* s) { delete s; }
 extern "C" int hjr_scene_get_view(const hjr_scene* s, hjr_scene_view* v)
 {
     if (!s || !v) { set_error("hjr_scene_get_view: null argument"); return HJR_ERR_ARG; }
+    hjr_scene_view* const user = v;
+    hjr_scene_view full; // sized struct: filled here, at most user->struct_size bytes handed out
+    v = &full;
     const hjr::SceneData& d = s->data;
     memset(v, 0, sizeof(*v));
+    v->struct_size = (uint32_t)sizeof(*v);
     v->n_vertices = (uint32_t)d.vertices.size();
     v->n_triangles = (uint32_t)(d.indices.size() / 3);
     v->n_instances = (uint32_t)d.instances.size();
@@ -85,7 +99,7 @@ extern "C" int hjr_scene_get_view(const hjr_scene* s, hjr_scene_view* v)
     v->light_prim_emission = d.light_prim_emission.empty() ? nullptr : &d.light_prim_emission[0].x;
     v->n_textures = (uint32_t)d.texture_views.size();
     v->textures = d.texture_views.data();
-    return HJR_OK;
+    return hjr::abi_give(user, full, "hjr_scene_get_view") ? HJR_OK : HJR_ERR_ARG;
 }
 
 extern "C" int hjr_scene_eval_transforms(const hjr_scene* s, float time, float* m12, float* inv12)
@@ -98,7 +112,9 @@ extern "C" int hjr_scene_eval_transforms(const hjr_scene* s, float time, float* 
 extern "C" int hjr_scene_eval_camera(const hjr_scene* s, const hjr_render_option* opt, float time, hjr_camera* out)
 {
     if (!s || !opt || !out) { set_error("hjr_scene_eval_camera: null argument"); return HJR_ERR_ARG; }
-    hjr::eval_camera(s->data, *opt, time, *out);
+    hjr_render_option o; // sized struct
+    if (!hjr::abi_take(opt, o, "hjr_scene_eval_camera")) return HJR_ERR_ARG;
+    hjr::eval_camera(s->data, o, time, *out);
     return HJR_OK;
 }
 
@@ -161,7 +177,9 @@ template <bool PACK> static int tiles_copy(const float* src, float* dst, uint32_
     if (!src || !dst || w == 0 || h == 0 || world == 0 || rank >= world) { set_error("hjr_pack_tiles / hjr_unpack_tiles: bad argument"); return HJR_ERR_ARG; }
     const uint32_t tiles_x = (w + 7u) / 8u, n = hjr_owned_tiles(w, h, rank, world);
     for (uint32_t i = 0; i < n; i++) {
-        const uint32_t tile = i * world + rank, x0 = (tile % tiles_x) * 8u, y0 = (tile / tiles_x) * 8u;
+        uint32_t tx, ty;
+        hjr_tile_xy(i * world + rank, tiles_x, &tx, &ty);
+        const uint32_t x0 = tx * 8u, y0 = ty * 8u;
         for (uint32_t k = 0; k < 64u; k++) {
             const uint32_t x = x0 + (k & 7u), y = y0 + (k >> 3);
             float* p = PACK ? dst + ((size_t)i * 64 + k) * 4 : nullptr;
@@ -214,6 +232,7 @@ extern "C" int hjr_render_file(const char* render_option_json, int device)
 {
     if (!render_option_json) { set_error("hjr_render_file: null path"); return HJR_ERR_ARG; }
     hjr_render_option opt;
+    HJR_INIT(opt);
     int rc = hjr_load_render_option(render_option_json, &opt);
     if (rc != HJR_OK) return rc;
     if (opt.render_mode != HJR_MODE_DEFAULT && opt.render_mode != HJR_MODE_DENOISE && opt.render_mode != HJR_MODE_DENOISE_UPSCALE2X) {
@@ -227,6 +246,7 @@ extern "C" int hjr_render_file(const char* render_option_json, int device)
     rc = hjr_create(device, &ctx);
     if (rc != HJR_OK) { hjr_scene_free(scene); return rc; }
     hjr_scene_view view;
+    HJR_INIT(view);
     hjr_scene_get_view(scene, &view);
     rc = hjr_upload_scene(ctx, &view);
     if (rc == HJR_OK) { // setLUT (renderer.h:854-898); a missing LUT file only matters if a material uses it
@@ -322,7 +342,7 @@ extern "C" int hjr_render_file(const char* render_option_json, int device)
         if (rc != HJR_OK) break;
         if (frame + 1 < opt.end_frame && !serial_io) prep = std::thread(prepare, frame + 1);
         hjr_params p;
-        memset(&p, 0, sizeof(p));
+        HJR_INIT(p);
         p.width = in_w; p.height = in_h;
         p.spp = opt.max_spp; p.frame = frame; p.seed = opt.seed; p.integrator = (uint32_t)opt.integrator;
         hjr_scene_eval_camera(scene, &opt, time, &p.camera);
@@ -339,6 +359,7 @@ extern "C" int hjr_render_file(const char* render_option_json, int device)
         else rc = hjr_render_denoised(ctx, &p, opt.render_mode, sl.color.data(), opt.image_width, opt.image_height); // renderer.h:1258-1281
         if (rc != HJR_OK) break;
         hjr_stats st;
+        HJR_INIT(st);
         if (hjr_get_stats(ctx, &st) == HJR_OK)
             fprintf(stderr, "[henjou] frame %u: %ux%u, %u spp, kernel %.3f ms (%.2f Msamples/s)\n", frame, p.width, p.height, p.spp,
                     st.last_kernel_ms, st.last_kernel_ms > 0 ? (double)p.width * p.height * p.spp / (st.last_kernel_ms * 1e3) : 0.0);

@@ -298,9 +298,9 @@ void emit_bvh2(const Builder& B, FrameData& out)
         const BuildNode& r = B.nodes[0];
         float* q = out.nodes.data();
         for (int c = 0; c < 2; c++)
-            for (int a = 0; a < 3; a++) { q[6 * c + a] = r.box.lo[a]; q[6 * c + 3 + a] = r.box.hi[a]; }
-        q[12] = u2f(leaf_ref(r.first, r.count));
-        q[13] = u2f(leaf_ref(0, 0));
+            for (int a = 0; a < 3; a++) { q[4 * a + c] = r.box.lo[a]; q[4 * a + 2 + c] = r.box.hi[a]; }
+        q[12] = q[14] = u2f(leaf_ref(r.first, r.count));
+        q[13] = q[15] = u2f(leaf_ref(0, 0));
         out.n_nodes = 1;
         out.stack_need = 2;
         return;
@@ -314,8 +314,8 @@ void emit_bvh2(const Builder& B, FrameData& out)
         const int cid[2] = { B.nodes[i].left, B.nodes[i].right };
         for (int c = 0; c < 2; c++) {
             const BuildNode& ch = B.nodes[(size_t)cid[c]];
-            for (int a = 0; a < 3; a++) { q[6 * c + a] = ch.box.lo[a]; q[6 * c + 3 + a] = ch.box.hi[a]; }
-            q[12 + c] = u2f(ch.left >= 0 ? (uint32_t)inner_id[(size_t)cid[c]] : leaf_ref(ch.first, ch.count));
+            for (int a = 0; a < 3; a++) { q[4 * a + c] = ch.box.lo[a]; q[4 * a + 2 + c] = ch.box.hi[a]; }
+            q[12 + c] = q[14 + c] = u2f(ch.left >= 0 ? (uint32_t)inner_id[(size_t)cid[c]] : leaf_ref(ch.first, ch.count)); // stored twice (hjr_layout.h)
         }
     }
 }

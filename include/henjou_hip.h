@@ -27,6 +27,17 @@ extern "C" {
 #define HJR_ERR_DEVICE (-4)  /* HIP runtime error, or no gfx950 device / kernel image */
 #define HJR_ERR_STATE (-5)   /* call order violated (render before upload, ...) */
 
+/* ---- Sized structs (the rule that keeps callers and library binary-compatible across releases) --------------------------------
+ * hjr_scene_view, hjr_render_option, hjr_params and hjr_stats may GROW at their end in later releases.  Each starts with
+ * `struct_size`: the CALLER sets it to sizeof(its own struct) before handing the struct to ANY entry point, input or output
+ * (HJR_INIT does it together with the zero fill).  The library copies min(struct_size, its own sizeof) bytes in either direction:
+ *   - a field the caller's (older, shorter) struct does not have is never written and reads as 0, which selects the default;
+ *   - a field a newer caller has and this library does not know is left untouched on output and ignored on input;
+ *   - struct_size == 0 (a struct that was zero-filled but not initialised) is rejected with HJR_ERR_ARG.
+ * The reference passes its launch block the same way: optixLaunch(..., d_param, sizeof(Params), ...) (renderer/renderer.h:1241).
+ * hjr_material, hjr_texture and hjr_camera are array elements / embedded records of fixed layout (reserved words inside). */
+#define HJR_INIT(s) do { memset(&(s), 0, sizeof(s)); (s).struct_size = (uint32_t)sizeof(s); } while (0) /* needs <string.h> */
+
 enum { HJR_INTEGRATOR_NEE = 0, HJR_INTEGRATOR_PT = 1, HJR_INTEGRATOR_MIS = 2 }; /* kernel/rt.h:162,85,284 */
 enum { HJR_MODE_DEFAULT = 0, HJR_MODE_DENOISE = 1, HJR_MODE_DENOISE_UPSCALE2X = 2, HJR_MODE_DEBUG = 3 }; /* renderer/render_option.h:38-43 */
 
@@ -70,6 +81,7 @@ typedef struct hjr_texture {
 
 /* Borrowed, read-only view of SceneData (renderer/scene.h:19-36).  The library copies on upload. */
 typedef struct hjr_scene_view {
+    uint32_t struct_size;    /* sizeof(hjr_scene_view) of the caller (HJR_INIT) */
     uint32_t n_vertices;     /* == 3 * n_triangles on the glTF path (de-indexed, gltfloader.h:1484-1492) */
     uint32_t n_triangles;
     uint32_t n_instances;    /* instance i <-> geometry i, 1:1 (gltfloader.h:1507-1512) */
@@ -77,7 +89,6 @@ typedef struct hjr_scene_view {
     uint32_t n_lights;       /* emissive triangles (gltfloader.h:1496-1500) */
     uint32_t n_animations;   /* == number of glTF nodes */
     uint32_t n_textures;     /* SceneData.textures (de-duplicated by file name, texture_load.h:7-20) */
-    uint32_t _reserved0;
     const float*    vertices;            /* float3 x n_vertices, object space */
     const float*    normals;             /* float3 x n_vertices */
     const float*    texcoords;           /* float2 x n_vertices */
@@ -95,6 +106,7 @@ typedef struct hjr_scene_view {
 
 /* Mirror of RenderOption (renderer/render_option.h:45-84). */
 typedef struct hjr_render_option {
+    uint32_t struct_size;        /* sizeof(hjr_render_option) of the caller (HJR_INIT) */
     uint32_t image_width, image_height;
     char image_name[256];
     char image_directory[512];
@@ -130,6 +142,7 @@ typedef struct hjr_camera {      /* Params.camera_* (renderer/renderer.h:1187-11
 
 /* Per-launch parameters: the scalar part of `Params` (renderer/renderer.h:1175-1227). */
 typedef struct hjr_params {
+    uint32_t struct_size;        /* sizeof(hjr_params) of the caller (HJR_INIT) */
     uint32_t width, height;      /* params.image_width/height */
     uint32_t spp;                /* params.spp */
     uint32_t frame;              /* params.frame */
@@ -138,17 +151,18 @@ typedef struct hjr_params {
     hjr_camera camera;
     float sky[3];                /* scene_sky_default: the 1x1 IBL texel (renderer/texture.h:58-65) */
     float ibl_intensity;         /* params.ibl_intensity */
-    uint32_t rank, world_size;   /* pixel-tile shard: this launch renders 8x8 tiles t with t % world_size == rank */
+    uint32_t rank, world_size;   /* pixel-tile shard: this launch renders the 8x8 tiles whose id t (see hjr_owned_tiles) has t % world_size == rank */
     uint32_t flags;              /* HJR_FLAG_* */
-    uint32_t _reserved;
 } hjr_params;
 #define HJR_FLAG_STATS 1u        /* run the counting variant of the kernel (slower; fills hjr_stats) */
 #define HJR_FLAG_ZERO_UNOWNED 2u /* clear pixels of tiles this rank does not own (for a sum-reduce exchange) */
-#define HJR_FLAG_PACKED 4u       /* hjr_render_device only: the AOV buffers are PACKED — this rank's tiles only, back to back, each
+#define HJR_FLAG_PACKED 4u       /* the AOV buffers (device or host) are PACKED — this rank's tiles only, back to back, each
                                   * tile 64 float4 in row-major 8x8 order (hjr_owned_tiles(..) x 64 float4 per AOV).  What a
                                   * multi-GPU frame exchanges: 1 / world_size of the frame per rank, no zero fill */
 
 typedef struct hjr_stats {
+    uint32_t struct_size;        /* sizeof(hjr_stats) of the caller (HJR_INIT) */
+    uint32_t _pad0;
     uint64_t samples, closest_rays, shadow_rays, box_tests_closest, tri_tests_closest,
              box_tests_shadow, tri_tests_shadow, shaded_hits, light_samples, nan_samples;
     float    last_kernel_ms;     /* HIP-event time of the last render kernel on its stream */
@@ -160,6 +174,10 @@ typedef struct hjr_stats {
     uint32_t stack_lds_entries;  /* memory-path layouts: entries of a lane's stack kept in LDS; deeper ones overflow to HBM */
     uint32_t pipeline;           /* 0 = persistent megakernel (a lane owns a path), 1 = workgroup-local wavefront kernel (trace / shade batches) */
     uint64_t stack_overflow_pushes; /* HJR_FLAG_STATS launches: stack pushes that went to the HBM overflow (memory-path layouts) */
+    /* HJR_FLAG_STATS launches: where NaN / Inf samples came from (they are zeroed and counted in nan_samples; the reference has no
+     * guard and would emit a NaN pixel): the first nan_located <= 8 of them in no particular order, as (pixel x, pixel y, sample) */
+    uint32_t nan_located, _pad1;
+    uint32_t nan_where[8][3];
 } hjr_stats;
 
 typedef struct hjr_scene hjr_scene; /* owning, host side (SceneData + animations) */
@@ -168,7 +186,8 @@ typedef struct hjr_ctx hjr_ctx;     /* one per device */
 const char* hjr_last_error(void);
 
 /* ---------------- scene surface: the file-level drop-in (host only, no GPU needed) ---------------- */
-/* load_json(filepath, RenderOption&) — loader/render_json_loader.h:78-228 (incl. ./fps.txt override, :164-171) */
+/* load_json(filepath, RenderOption&) — loader/render_json_loader.h:78-228 (incl. ./fps.txt override, :164-171).
+ * `out` must carry its struct_size (HJR_INIT) before the call, like every sized struct. */
 int hjr_load_render_option(const char* json_path, hjr_render_option* out);
 /* gltfloader(filepath, filename, SceneData&, RenderOption&) — loader/gltfloader.h:1068-1601 */
 int hjr_scene_load_gltf(const char* dir, const char* file, hjr_render_option* opt_inout, hjr_scene** out);
@@ -213,7 +232,9 @@ int hjr_render_device(hjr_ctx*, const hjr_params*, void* d_aov_color, void* d_ao
                       void* hip_stream);
 int hjr_synchronize(hjr_ctx*);
 /* ---- pixel-tile shard helpers (no reference counterpart: the reference is single-GPU, renderer.h:1077-1078) ----
- * Tiles are 8x8 pixels, numbered row-major, tile t belongs to rank t % world_size; rank r's i-th tile is i * world_size + r. */
+ * Tiles are 8x8 pixels; tile (tx, ty) has id t = ty * tiles_x + (tx + ty) % tiles_x (row ty of tiles rotated by ty places, so that a
+ * rank's tiles run along diagonals instead of forming vertical stripes when tiles_x is a multiple of world_size); tile t belongs to
+ * rank t % world_size and is that rank's (t / world_size)-th tile. */
 uint32_t hjr_owned_tiles(uint32_t width, uint32_t height, uint32_t rank, uint32_t world_size);
 /* host arrays: row-major float4 frame <-> packed [owned tile][64] float4 of one rank (frame pixels of other ranks untouched) */
 int hjr_pack_tiles(const float* frame_rgba, uint32_t width, uint32_t height, uint32_t rank, uint32_t world_size, float* packed_rgba);

@@ -1350,13 +1350,14 @@ static void sample_one(tctx* T, uint32_t x, uint32_t y, uint32_t s, f3* L, f3* A
     if (!(sum - sum == 0.0f)) { *L = V1(0.0f); T->st.nan_samples++; } /* NaN/Inf guard (build-defined) */
 }
 
-void hjo_sample(hjo_ctx* c, const hjo_params* P, uint32_t x, uint32_t y, uint32_t s, float* rad, float* alb, float* nor)
+int hjo_sample(hjo_ctx* c, const hjo_params* P, uint32_t x, uint32_t y, uint32_t s, float* rad, float* alb, float* nor)
 {
     tctx T; memset(&T, 0, sizeof(T)); T.c = c; T.P = P; T.right = g_right_of(c);
     f3 L, A, N; sample_one(&T, x, y, s, &L, &A, &N);
     rad[0] = L.x; rad[1] = L.y; rad[2] = L.z;
     if (alb) { alb[0] = A.x; alb[1] = A.y; alb[2] = A.z; }
     if (nor) { nor[0] = N.x; nor[1] = N.y; nor[2] = N.z; }
+    return (int)T.st.nan_samples; /* 1: the sample was NaN / Inf and has been zeroed by the guard */
 }
 
 typedef struct { tctx T; float *color, *albedo, *normal; volatile uint32_t* next_row; uint32_t x0, y0, x1, y1; } job;

@@ -100,7 +100,7 @@ void     hjo_destroy(hjo_ctx*);
 int hjo_render(hjo_ctx*, const hjo_params*, float* color, float* albedo, float* normal,
                int nthreads, hjo_stats* stats);
 /* One (pixel, sample): radiance[3], albedo[3], normal[3]. */
-void hjo_sample(hjo_ctx*, const hjo_params*, uint32_t x, uint32_t y, uint32_t s,
+int hjo_sample(hjo_ctx*, const hjo_params*, uint32_t x, uint32_t y, uint32_t s,
                 float* radiance, float* albedo, float* normal);
 
 /* Ray queries (bvh=0: brute force over all triangles; bvh=1: through the BVH).

@@ -26,6 +26,7 @@ int main(int argc, char** argv)
     const std::string assets = argv[1], config = argv[2], tmp = argv[3];
     std::string err;
     hjr_render_option opt;
+    HJR_INIT(opt);
     CHECK(hjr::load_render_option(assets + "/" + config, opt, err));
     hjr::SceneData sc;
     CHECK(hjr::load_gltf(assets + "/" + opt.gltf_path, opt.gltf_name, sc, opt, err));

@@ -127,6 +127,7 @@ def lib():
         L.hjo_destroy.argtypes = [C.c_void_p]
         L.hjo_render.restype = C.c_int
         L.hjo_render.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.hjo_sample.restype = C.c_int
         L.hjo_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p,
                                  C.c_void_p, C.c_void_p]
         L.hjo_trace_closest.restype = C.c_int
@@ -219,6 +220,11 @@ class OracleScene:
         r, a, n = F3(), F3(), F3()
         lib().hjo_sample(self.ctx, C.byref(params), x, y, s, r, a, n)
         return np.array(r, dtype=np.float32), np.array(a, dtype=np.float32), np.array(n, dtype=np.float32)
+
+    def sample_is_nan(self, params, x, y, s):
+        """True when sample s of pixel (x, y) is NaN / Inf on the oracle (zeroed and counted by the guard, like the product's)."""
+        r, a, n = F3(), F3(), F3()
+        return lib().hjo_sample(self.ctx, C.byref(params), x, y, s, r, a, n) != 0
 
     def trace_closest(self, o, d, tmin=0.001, tmax=1e16, use_bvh=1):
         out = F3()

@@ -30,9 +30,11 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_header():
     assert C.sizeof(hjr.Material) == 80 and hjr.MATERIAL_DTYPE.itemsize == 80 and C.sizeof(hjr.Texture) == 24
     assert C.sizeof(hjr.Camera) == 52
-    assert C.sizeof(hjr.Params) == 6 * 4 + 52 + 12 + 4 + 16
-    assert C.sizeof(hjr.Stats) == 10 * 8 + 16 + 16 + 8
+    assert C.sizeof(hjr.Params) == 4 + 6 * 4 + 52 + 12 + 4 + 12
+    assert C.sizeof(hjr.Stats) == 8 + 10 * 8 + 16 + 16 + 8 + 8 + 96
     assert C.sizeof(hjr.SceneView) == 8 * 4 + 13 * 8
+    for t in (hjr.Params, hjr.Stats, hjr.SceneView, hjr.RenderOption): # sized structs: struct_size leads and is set on construction
+        assert t.struct_size.offset == 0 and t().struct_size == C.sizeof(t)
 
 
 def test_stack16_encoding_roundtrips_every_ref_the_builder_can_emit():

@@ -52,3 +52,14 @@ def test_bench_two_rank_rehearsal():
              "--warmup", "1"], env=env)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and "cpu_baseline" not in d
     assert "gather" in d["config"]["parallelism"]
+
+
+def test_bench_gpus_2_started_plainly_launches_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher: bench.py starts torch.distributed.run itself as a child process and relays rank 0's
+    line (rehearsal knobs: both ranks on GPU 0, gloo in place of RCCL — two RCCL ranks need two GPUs)."""
+    env = dict(os.environ, HJR_BENCH_DEVICE="0", HJR_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    d = run([sys.executable, "bench.py", "--gpus", "2", "--width", "320", "--height", "200", "--spp", "32", "--steps", "1", "--warmup", "1"], env=env)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    assert "gather" in d["config"]["parallelism"]

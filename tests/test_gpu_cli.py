@@ -71,7 +71,7 @@ def test_cli_rank_process_path_on_one_gpu(tmp_path):
     ro["Image"]["image_name"] = "b"
     (work / "render_option.json").write_text(json.dumps(ro))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    q = subprocess.run([CLI, "render_option.json", "--rank", "0", "--world", "1", "--id", str(work / "rccl_id")], cwd=work, capture_output=True,
+    q = subprocess.run([CLI, "render_option.json", "--rank", "0", "--world", "1"], cwd=work, capture_output=True,
                        text=True, timeout=300, env=env)
     assert q.returncode == 0, q.stdout + q.stderr
     assert (work / "b_001.png").read_bytes() == single

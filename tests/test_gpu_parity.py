@@ -186,8 +186,8 @@ def test_c5_shard_3840x2160_4096spp(cornell, dev):
     w, h, spp, R, r = 3840, 2160, 4096, 8, 3
     tiles_x = w // 8
     # pick an 8x8 tile owned by rank 3 near the sphere and render only a narrow band of the frame on the oracle side
-    ty, tx = 150, 243
-    assert (ty * tiles_x + tx) % R == r
+    ty, tx = 150, 245
+    assert (ty * tiles_x + (tx + ty) % tiles_x) % R == r  # tile ids: rows rotated by ty (csrc/hjr_layout.h)
     p = cornell.hjr_params(w, h, spp, rank=r, world_size=R)
     # the full shard would be 4.2e9 samples (~2 s); keep the test light by rendering it once, colour only
     color, _, _ = dev.render(p, want_aovs=False)
@@ -198,3 +198,27 @@ def test_c5_shard_3840x2160_4096spp(cornell, dev):
     rect = (tx * 8, ty * 8, tx * 8 + 8, ty * 8 + 4)
     oc, _, _, _ = osc.render(cornell.oracle_params(w, h, spp, rect=rect), want_aovs=False)
     assert_bitexact(color[rect[1]:rect[3], rect[0]:rect[2]], oc[rect[1]:rect[3], rect[0]:rect[2]], "C5 window")
+
+
+def test_nan_samples_of_the_full_frame_are_the_oracles(cornell, dev, oracle):
+    """The C2 frame (1920x1080, 256 spp) holds a few NaN samples: the product zeroes and counts them, and a counting
+    launch says where they are (hjr_stats.nan_where).  Every one of them must be a NaN sample of the oracle too, and the 8x8 tiles
+    around them — windows whose NaN count is not zero — must match the oracle bit for bit, guard included."""
+    w, h, spp = 1920, 1080, 256
+    color, _, _ = dev.render(cornell.hjr_params(w, h, spp, flags=hjr.FLAG_STATS), want_aovs=False)
+    st = dev.stats()
+    assert st["samples"] == w * h * spp
+    assert 0 < st["nan_samples"] <= 8 and len(st["nan_where"]) == st["nan_samples"], st
+    op = cornell.oracle_params(w, h, spp)
+    for (x, y, s) in st["nan_where"]:
+        assert oracle.sample_is_nan(op, x, y, s), "sample %d of pixel (%d, %d) is NaN on the GPU only" % (s, x, y)
+    seen = 0
+    for (x, y, s) in sorted(set((x // 8 * 8, y // 8 * 8, 0) for (x, y, _) in st["nan_where"])):
+        rect = (x, y, x + 8, y + 8)
+        oc, _, _, ost = oracle.render(cornell.oracle_params(w, h, spp, rect=rect), want_aovs=False)
+        assert ost["nan_samples"] >= 1
+        seen += ost["nan_samples"]
+        assert_bitexact(color[y:y + 8, x:x + 8], oc[y:y + 8, x:x + 8], "tile with a NaN sample at (%d, %d)" % (x, y))
+    assert seen == st["nan_samples"]  # the tiles hold no NaN sample the GPU did not report
+    plain, _, _ = dev.render(cornell.hjr_params(w, h, spp), want_aovs=False)
+    assert_bitexact(plain, color, "counting launch vs plain launch")

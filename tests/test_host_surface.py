@@ -200,3 +200,44 @@ def test_glb_container(tmp_path):
     (tmp_path / "bad.glb").write_bytes(blob[:40])
     with pytest.raises(hjr.HjrError):
         hjr.Scene(str(tmp_path), "bad.glb", opt)
+
+
+def test_reference_shipped_config_verbatim(tmp_path):
+    """The one piece of reference-held DATA on this boundary: the render_option.json + fps.txt the reference ships in its working
+    directory (committed verbatim under tests/golden/ref_config/), parsed by the product's loader; every field against the value
+    written in the file (render_json_loader.h:97-202), then the file-level entry point on it: the glTF it names is not in the
+    reference repository, so hjr_render_file must fail with HJR_ERR_IO naming that file — before any GPU call."""
+    ref = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_config")
+    for f in ("render_option.json", "fps.txt"):
+        shutil.copy(os.path.join(ref, f), str(tmp_path / f))
+    cwd = os.getcwd()
+    os.chdir(str(tmp_path))  # load_json reads ./fps.txt of the working directory (render_json_loader.h:164)
+    try:
+        o = hjr.load_render_option("render_option.json")
+        rc = hjr.lib().hjr_render_file(b"render_option.json", 0)
+        err = hjr.lib().hjr_last_error().decode()
+    finally:
+        os.chdir(cwd)
+    assert (o.image_width, o.image_height, o.max_spp) == (1280, 720, 5000)
+    assert o.image_name == b"multiple_scattering_ggx" and o.image_directory == b"./"
+    assert o.render_mode == hjr.MODE_DEFAULT
+    assert o.gltf_path == b"./Model/White_FurnanceTest/GLTF/" and o.gltf_name == b"WhiteFurnanceTest_Roghness.gltf"
+    assert o.allow_camera_animation == 1
+    assert list(o.camera_position) == [0.0, 1.0, -7.0] and list(o.camera_direction) == [0.0, 0.0, 1.0]
+    assert np.float32(o.camera_fov) == np.float32(np.pi * 45.0 / 180.0)  # 45 degrees -> radians (render_json_loader.h:144)
+    assert o.ptxfile_path == b"../lib/ptx/Release/HenjouRenderer_generated_henjouRendererCU.cu.optixir"
+    assert (o.fps, o.start_frame, o.end_frame) == (24, 1, 2) and o.time_limit == 5.0  # fps.txt holds 24 as well
+    assert o.IBL_path == b"./HDRI/blocky_photo_studio_4k.hdr" and o.IBL_intensity == 1.0 and o.use_IBL == 0
+    assert [np.float32(x) for x in o.scene_sky_default] == [np.float32(0.8)] * 3
+    assert o.use_date == 1 and o.save_renderOption == 0
+    assert o.LUT_path == b"./LUT/Thin_Film_LUT.png"
+    assert (o.seed, o.integrator, o.devices, o.tile) == (1, hjr.INTEGRATOR_NEE, 1, 8)  # no Henjou_HIP section: defaults
+    assert rc == -2, (rc, err)  # HJR_ERR_IO
+    assert "WhiteFurnanceTest_Roghness.gltf" in err
+    # the override file is honoured: another rate in ./fps.txt wins over the JSON's (render_json_loader.h:14-34, 164-171)
+    (tmp_path / "fps.txt").write_text("30")
+    os.chdir(str(tmp_path))
+    try:
+        assert hjr.load_render_option("render_option.json").fps == 30
+    finally:
+        os.chdir(cwd)

@@ -40,3 +40,32 @@ def test_henjou_hip_section_devices_and_tile(tmp_path):
         b.write_text(json.dumps(base))
         with pytest.raises(hjr.HjrError):
             hjr.load_render_option(str(b))
+
+
+@pytest.mark.parametrize("w,h,n", [(1920, 1080, 8), (3840, 2160, 8), (1920, 1080, 4), (1920, 1080, 2), (75, 41, 3)])
+def test_tile_ids_partition_the_frame_and_run_along_diagonals(w, h, n):
+    """Tile ids rotate every row of tiles by its row number (csrc/hjr_layout.h): still a partition with the round-robin tile counts
+    of hjr_owned_tiles, the library's pack / unpack agree with the Python mask, and when tiles_x is a multiple of the GPU count (1080p
+    and 4K on 2 / 4 / 8 GPUs) a rank no longer owns fixed vertical stripes: every column of tiles meets every rank."""
+    import numpy as np
+    masks = [hjr.owned_tile_mask(w, h, r, n) for r in range(n)]
+    assert np.array_equal(np.sum(masks, axis=0), np.ones((h, w), dtype=np.int64))
+    tiles = [m[::8, ::8] for m in masks]
+    for r in range(n):
+        assert int(tiles[r].sum()) == hjr.lib().hjr_owned_tiles(w, h, r, n)
+    owner = np.zeros(tiles[0].shape, dtype=np.int64)
+    for r in range(n):
+        owner[tiles[r]] = r
+    if owner.shape[0] >= n:
+        for col in range(owner.shape[1]):
+            assert len(set(owner[:, col].tolist())) == n, "tile column %d belongs to a subset of the ranks" % col
+    # the library's own numbering: pack rank 1's tiles of a frame that stores (x, y) in every pixel and look at what arrived
+    frame = np.zeros((h, w, 4), dtype=np.float32)
+    frame[..., 0] = np.arange(w, dtype=np.float32)[None, :]
+    frame[..., 1] = np.arange(h, dtype=np.float32)[:, None]
+    frame[..., 3] = 1.0
+    r = 1 % n
+    packed = hjr.pack_tiles(frame, r, n)
+    inside = packed[..., 3] == 1.0
+    xs, ys = packed[..., 0][inside].astype(np.int64), packed[..., 1][inside].astype(np.int64)
+    assert masks[r][ys, xs].all() and inside.sum() == masks[r].sum()

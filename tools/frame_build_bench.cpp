@@ -19,6 +19,7 @@ int main(int argc, char** argv)
     const int reps = argc > 3 ? atoi(argv[3]) : 3;
     std::string err;
     hjr_render_option opt;
+    HJR_INIT(opt);
     if (!hjr::load_render_option(dir + "/" + config, opt, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
     hjr::SceneData sc;
     if (!hjr::load_gltf((opt.gltf_path[0] == 0x2f ? std::string() : dir + "/") + opt.gltf_path, opt.gltf_name, sc, opt, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }

@@ -27,6 +27,7 @@ int main(int argc, char** argv)
     SYM(hjr_scene_eval_camera) SYM(hjr_load_png_rgba8) SYM(hjr_free) SYM(hjr_create) SYM(hjr_upload_scene) SYM(hjr_set_transforms)
     SYM(hjr_set_lut) SYM(hjr_render) SYM(hjr_get_stats) SYM(hjr_destroy)
     hjr_render_option opt;
+    HJR_INIT(opt);
 #define CHK(call) do { int rc_ = (call); if (rc_ != HJR_OK) { fprintf(stderr, "kbench: %s -> %d: %s\n", #call, rc_, p_hjr_last_error()); return 1; } } while (0)
     CHK(p_hjr_load_render_option(argv[2], &opt));
     int reps = 3, rank = 0, world = 1;
@@ -48,6 +49,7 @@ int main(int argc, char** argv)
     hjr_scene* scene = nullptr;
     CHK(p_hjr_scene_load_gltf(opt.gltf_path, opt.gltf_name, &opt, &scene));
     hjr_scene_view view;
+    HJR_INIT(view);
     CHK(p_hjr_scene_get_view(scene, &view));
     hjr_ctx* ctx = nullptr;
     CHK(p_hjr_create(0, &ctx));
@@ -61,18 +63,19 @@ int main(int argc, char** argv)
     CHK(p_hjr_scene_eval_transforms(scene, time, m.data(), inv.data()));
     CHK(p_hjr_set_transforms(ctx, m.data(), inv.data(), view.n_instances));
     hjr_params p;
-    memset(&p, 0, sizeof(p));
+    HJR_INIT(p);
     p.width = opt.image_width; p.height = opt.image_height; p.spp = opt.max_spp; p.frame = opt.start_frame; p.seed = opt.seed;
     p.integrator = (uint32_t)opt.integrator;
     CHK(p_hjr_scene_eval_camera(scene, &opt, time, &p.camera));
     for (int k = 0; k < 3; k++) p.sky[k] = opt.scene_sky_default[k];
     p.ibl_intensity = opt.IBL_intensity;
     p.rank = (uint32_t)rank; p.world_size = (uint32_t)world;
-    p.flags = (stats ? HJR_FLAG_STATS : 0u) | (world > 1 ? HJR_FLAG_ZERO_UNOWNED : 0u);
+    p.flags = (stats ? HJR_FLAG_STATS : 0u) | (world > 1 ? HJR_FLAG_PACKED : 0u); // a rank of a shard renders packed tiles, as bench.py and henjou_cli do
     const size_t npx = (size_t)p.width * p.height;
     std::vector<float> color(npx * 4), albedo(aovs ? npx * 4 : 0), normal(aovs ? npx * 4 : 0);
     double sum = 0, best = 1e30;
     hjr_stats st;
+    HJR_INIT(st);
     for (int r = 0; r < reps + 1; r++) { // first launch is the warm-up
         CHK(p_hjr_render(ctx, &p, color.data(), aovs ? albedo.data() : nullptr, aovs ? normal.data() : nullptr));
         CHK(p_hjr_get_stats(ctx, &st));
@@ -95,6 +98,7 @@ int main(int argc, char** argv)
                       (unsigned long long)st.samples, (unsigned long long)st.closest_rays, (unsigned long long)st.shadow_rays, (unsigned long long)st.box_tests_closest,
                       (unsigned long long)st.tri_tests_closest, (unsigned long long)st.box_tests_shadow, (unsigned long long)st.tri_tests_shadow,
                       (unsigned long long)st.shaded_hits, (unsigned long long)st.light_samples, (unsigned long long)st.nan_samples);
+    if (stats) for (uint32_t i = 0; i < st.nan_located; i++) printf("  nan sample at x %u y %u s %u\n", st.nan_where[i][0], st.nan_where[i][1], st.nan_where[i][2]);
     p_hjr_destroy(ctx);
     return 0;
 }

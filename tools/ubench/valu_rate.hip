@@ -24,6 +24,23 @@ template <int OP> __global__ void k(uint32_t* out, uint64_t* cyc, uint32_t seed)
                 if (OP == 5) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(*(uint64_t*)&a[i & 6]) : "v"(b), "v"(b) : "vcc");
                 if (OP == 6) asm volatile("v_sqrt_f32_e32 %0, %0" : "+v"(a[i]));
                 if (OP == 7) asm volatile("v_pk_mul_f32 %0, %0, %0" : "+v"(*(uint64_t*)&a[i & 6]));
+                if (OP == 8) asm volatile("v_pk_fma_f32 %0, %0, %0, %0" : "+v"(*(uint64_t*)&a[i & 6]));
+                if (OP == 9) asm volatile("v_pk_add_f32 %0, %0, %0" : "+v"(*(uint64_t*)&a[i & 6]));
+                if (OP == 10) asm volatile("v_add_u32_e32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+                if (OP == 11) asm volatile("v_lshl_add_u32 %0, %0, 6, %1" : "+v"(a[i]) : "v"(b));
+                if (OP == 12) asm volatile("v_max3_f32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(b));
+                if (OP == 13) asm volatile("v_min_f32_e32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+                if (OP == 14) asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(b) : "vcc");
+                if (OP == 15) asm volatile("v_cmp_le_f32_e32 vcc, %0, %1" : : "v"(a[i]), "v"(b) : "vcc");
+                if (OP == 16) asm volatile("v_mul_f32_e32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+                if (OP == 17) asm volatile("v_add_f32_e32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+                if (OP == 18) asm volatile("v_mov_b32_e32 %0, %1" : "+v"(a[i]) : "v"(b));
+                if (OP == 19) asm volatile("v_fmac_f32_e32 %0, %1, %1" : "+v"(a[i]) : "v"(b));
+                if (OP == 20) asm volatile("v_and_b32_e32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+                if (OP == 21) asm volatile("v_lshlrev_b32_e32 %0, 3, %0" : "+v"(a[i]));
+                if (OP == 22) asm volatile("v_readlane_b32 s20, %0, 3" : : "v"(a[i]) : "s20");
+                if (OP == 23) asm volatile("s_nop 0");
+                if (OP == 24) asm volatile("v_pk_mov_b32 %0, %0, %0" : "+v"(*(uint64_t*)&a[i & 6]));
             }
         }
     }
@@ -57,5 +74,8 @@ int main()
 {
     run<0>("v_mul_lo_u32"); run<1>("v_mul_u32_u24"); run<2>("v_fma_f32"); run<3>("v_rcp_f32"); run<4>("v_xor_b32");
     run<5>("v_mad_u64_u32"); run<6>("v_sqrt_f32"); run<7>("v_pk_mul_f32");
+    run<8>("v_pk_fma_f32"); run<9>("v_pk_add_f32"); run<10>("v_add_u32"); run<11>("v_lshl_add_u32"); run<12>("v_max3_f32"); run<13>("v_min_f32");
+    run<14>("v_cndmask_b32"); run<15>("v_cmp_le_f32"); run<16>("v_mul_f32"); run<17>("v_add_f32"); run<18>("v_mov_b32"); run<19>("v_fmac_f32");
+    run<20>("v_and_b32"); run<21>("v_lshlrev_b32"); run<22>("v_readlane_b32"); run<23>("s_nop"); run<24>("v_pk_mov_b32");
     return 0;
 }

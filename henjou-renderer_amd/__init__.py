@@ -76,7 +76,7 @@ class RenderOption(_Sized):
                 ("use_IBL", C.c_int32), ("IBL_path", C.c_char * 512), ("IBL_intensity", C.c_float),
                 ("scene_sky_default", C.c_float * 3), ("use_date", C.c_int32), ("save_renderOption", C.c_int32),
                 ("LUT_path", C.c_char * 512), ("seed", C.c_uint32), ("integrator", C.c_int32),
-                ("devices", C.c_uint32), ("tile", C.c_uint32)]
+                ("devices", C.c_uint32), ("tile", C.c_uint32), ("serial_io", C.c_int32), ("fast_math", C.c_int32)]
 
 
 class Camera(C.Structure):
@@ -147,6 +147,8 @@ def lib():
             "hjr_render_device": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
             "hjr_synchronize": [C.c_void_p],
             "hjr_get_stats": [C.c_void_p, C.c_void_p],
+            "hjr_set_option": [C.c_void_p, C.c_char_p, C.c_int],
+            "hjr_get_option": [C.c_void_p, C.c_char_p, C.c_void_p],
             "hjr_float4_to_srgb8": [C.c_void_p, C.c_void_p, C.c_uint32],
             "hjr_tonemap_to_srgb8": [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int],
             "hjr_write_png": [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int],
@@ -416,6 +418,15 @@ class Device:
 
     def synchronize(self):
         _check(lib().hjr_synchronize(self._h), "hjr_synchronize")
+
+    def set_option(self, key, value):
+        """hjr_set_option: tuning / test option of this context (-1 restores the default); layout options act at the next set_transforms."""
+        _check(lib().hjr_set_option(self._h, key.encode(), int(value)), "hjr_set_option")
+
+    def get_option(self, key):
+        v = C.c_int()
+        _check(lib().hjr_get_option(self._h, key.encode(), C.byref(v)), "hjr_get_option")
+        return v.value
 
     def stats(self):
         st = Stats()

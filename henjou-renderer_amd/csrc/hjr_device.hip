@@ -50,7 +50,14 @@ extern "C" int hjr_create(int device, hjr_ctx** out)
     c->device = device;
     c->n_cus = prop.multiProcessorCount;
     memset(&c->stats, 0, sizeof(c->stats));
-    if (const char* b = getenv("HJR_BLOCKS_PER_CU")) { int v = atoi(b); if (v >= 1 && v <= 8) c->blocks_per_cu = v; }
+#ifdef HJR_ENV_OPTIONS /* experiment builds only (make variant): every option also from the environment, HJR_<KEY> */
+    for (int i = 0; i < hjr::OPT_COUNT; i++) {
+        std::string name = std::string("HJR_") + hjr::opt_table()[i].key;
+        for (char& ch : name) ch = (char)toupper((unsigned char)ch);
+        if (const char* e = getenv(name.c_str())) { const int v = atoi(e); if (v >= hjr::opt_table()[i].lo && v <= hjr::opt_table()[i].hi) c->opt.v[i] = v; }
+    }
+    if (c->opt.is_set(hjr::OPT_HOST_THREADS)) hjr::set_host_threads(c->opt.v[hjr::OPT_HOST_THREADS]);
+#endif
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess ||
         hipEventCreate(&c->ev1) != hipSuccess) {
         set_error("hjr_create: stream/event creation failed");
@@ -58,6 +65,30 @@ extern "C" int hjr_create(int device, hjr_ctx** out)
         return HJR_ERR_DEVICE;
     }
     *out = c;
+    return HJR_OK;
+}
+
+// Tuning / test options (host/options.hpp lists keys, ranges and defaults; include/henjou_hip.h documents them)
+extern "C" int hjr_set_option(hjr_ctx* c, const char* key, int value)
+{
+    if (!c) { set_error("hjr_set_option: null context"); return HJR_ERR_ARG; }
+    const int i = hjr::opt_find(key);
+    if (i < 0) { set_error(std::string("hjr_set_option: unknown option \"") + (key ? key : "(null)") + "\""); return HJR_ERR_ARG; }
+    const hjr::OptDesc& d = hjr::opt_table()[i];
+    if (value != -1 && (value < d.lo || value > d.hi || (i == hjr::OPT_BVH_WIDTH && value == 3) || (i == hjr::OPT_WF_CAP && (value & (value - 1)) != 0))) {
+        set_error(std::string("hjr_set_option: value out of range for \"") + d.key + "\" (" + std::to_string(d.lo) + " .. " + std::to_string(d.hi) + ", or -1 for the default)");
+        return HJR_ERR_ARG;
+    }
+    c->opt.v[i] = value;
+    if (i == hjr::OPT_HOST_THREADS) hjr::set_host_threads(value);
+    return HJR_OK;
+}
+extern "C" int hjr_get_option(hjr_ctx* c, const char* key, int* value)
+{
+    if (!c || !value) { set_error("hjr_get_option: null argument"); return HJR_ERR_ARG; }
+    const int i = hjr::opt_find(key);
+    if (i < 0) { set_error(std::string("hjr_get_option: unknown option \"") + (key ? key : "(null)") + "\""); return HJR_ERR_ARG; }
+    *value = c->opt.v[i];
     return HJR_OK;
 }
 
@@ -121,23 +152,28 @@ extern "C" int hjr_prepare_transforms(hjr_ctx* c, const float* m, const float* i
     if (!c || (n && (!m || !inv))) { set_error("hjr_set_transforms: null argument"); return HJR_ERR_ARG; }
     if (!c->have_scene) { set_error("hjr_set_transforms: no scene uploaded"); return HJR_ERR_STATE; }
     std::string err;
-    bool allow_lds = true;
-    if (const char* e = getenv("HJR_LDS_BVH")) allow_lds = atoi(e) != 0;
+    hjr::BuildOptions bo; // options "lds_bvh", "lds_stack16", "bvh_width", "leaf_max", "verbose" (host build stages)
+    bo.allow_lds = c->opt.get(hjr::OPT_LDS_BVH, 1) != 0;
+    bo.prefer_stack16 = c->opt.get(hjr::OPT_LDS_STACK16, 0) != 0;
+    bo.bvh_width = c->opt.get(hjr::OPT_BVH_WIDTH, -1);
+    bo.leaf_max = c->opt.get(hjr::OPT_LEAF_MAX, -1);
+    bo.timing = c->opt.get(hjr::OPT_VERBOSE, 0) != 0;
+    const uint32_t build_tag = (bo.allow_lds ? 1u : 0u) | (bo.prefer_stack16 ? 2u : 0u) | ((uint32_t)(bo.bvh_width + 1) << 2) | ((uint32_t)(bo.leaf_max + 1) << 6);
     c->pending_valid = false;
     c->pending_same = false;
     // unchanged instance transforms (static geometry, e.g. a camera-only animation): the world-space arrays and the BVH of the
     // previous frame are still right; the reference re-uploads its IAS every frame (renderer.h:257-291), which costs it nothing
-    static const bool force_rebuild = getenv("HJR_FORCE_REBUILD") && atoi(getenv("HJR_FORCE_REBUILD")) != 0; // benchmarking knob
-    if (!force_rebuild && c->have_frame && c->last_allow_lds == allow_lds && c->last_m.size() == (size_t)n * 12 && n == c->scene.n_instances &&
+    const bool force_rebuild = c->opt.get(hjr::OPT_FORCE_REBUILD, 0) != 0; // benchmarking option
+    if (!force_rebuild && c->have_frame && c->last_build_tag == build_tag && c->last_m.size() == (size_t)n * 12 && n == c->scene.n_instances &&
         (n == 0 || (memcmp(c->last_m.data(), m, (size_t)n * 48) == 0 && memcmp(c->last_inv.data(), inv, (size_t)n * 48) == 0))) {
         c->pending_same = true;
         c->pending_valid = true;
         return HJR_OK;
     }
     const auto t_build0 = std::chrono::steady_clock::now();
-    if (!hjr::build_frame(c->scene, m, inv, n, allow_lds, c->pending, err)) { set_error("hjr_set_transforms: " + err); return HJR_ERR_ARG; }
+    if (!hjr::build_frame(c->scene, m, inv, n, bo, c->pending, err)) { set_error("hjr_set_transforms: " + err); return HJR_ERR_ARG; }
     c->pending_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_build0).count();
-    c->pending_m.assign(m, m + (size_t)n * 12); c->pending_inv.assign(inv, inv + (size_t)n * 12); c->pending_allow_lds = allow_lds;
+    c->pending_m.assign(m, m + (size_t)n * 12); c->pending_inv.assign(inv, inv + (size_t)n * 12); c->pending_build_tag = build_tag;
     c->pending_valid = true;
     return HJR_OK;
 }
@@ -148,7 +184,7 @@ extern "C" int hjr_commit_transforms(hjr_ctx* c)
     if (!c->pending_valid) { set_error("hjr_commit_transforms: nothing prepared"); return HJR_ERR_STATE; }
     c->pending_valid = false;
     if (c->pending_same) {
-        if (getenv("HJR_VERBOSE")) fprintf(stderr, "[hjr] transforms unchanged: frame data reused\n");
+        if (c->opt.get(hjr::OPT_VERBOSE, 0)) fprintf(stderr, "[hjr] transforms unchanged: frame data reused\n");
         return HJR_OK;
     }
     HIPCHK(hipSetDevice(c->device));
@@ -162,10 +198,10 @@ extern "C" int hjr_commit_transforms(hjr_ctx* c)
     if (!ok) { c->have_frame = false; set_error("hjr_set_transforms: device upload failed"); return HJR_ERR_DEVICE; }
     HIPCHK(hipStreamSynchronize(c->stream));
     c->have_frame = true;
-    c->last_m.swap(c->pending_m); c->last_inv.swap(c->pending_inv); c->last_allow_lds = c->pending_allow_lds;
+    c->last_m.swap(c->pending_m); c->last_inv.swap(c->pending_inv); c->last_build_tag = c->pending_build_tag;
     c->stats.bvh_nodes = f.n_nodes;
     c->stats.bvh_depth = f.depth;
-    if (getenv("HJR_VERBOSE")) fprintf(stderr, "[hjr] BVH%u (lds_mode %d): %u nodes (%zu KB), %u triangles (%zu KB), stack %u entries/lane, host build %.1f ms\n", f.width, f.lds_mode, f.n_nodes, f.nodes.size() * 4 / 1024, f.n_tris, f.tri_geom.size() * 4 / 1024, f.stack_need, c->pending_build_ms);
+    if (c->opt.get(hjr::OPT_VERBOSE, 0)) fprintf(stderr, "[hjr] BVH%u (lds_mode %d): %u nodes (%zu KB), %u triangles (%zu KB), stack %u entries/lane, host build %.1f ms\n", f.width, f.lds_mode, f.n_nodes, f.nodes.size() * 4 / 1024, f.n_tris, f.tri_geom.size() * 4 / 1024, f.stack_need, c->pending_build_ms);
     c->stats.n_triangles = f.n_tris;
     return HJR_OK;
 }
@@ -319,7 +355,8 @@ static int render_impl(hjr_ctx* c, const hjr_params* p, void* d_color, void* d_a
     c->stats.stack_lds_entries = 0; // set by the memory-path launch
     HIPCHK(hipEventRecord(c->ev0, st));
     // cost-ordered tile list (hjr_classify_tiles_kernel): HJR_TILE_ORDER=0 keeps the plain round-robin order
-    static const bool tile_order_on = !(getenv("HJR_TILE_ORDER") && atoi(getenv("HJR_TILE_ORDER")) == 0);
+    const int order_knob = c->opt.get(hjr::OPT_TILE_ORDER, -1); // option "tile_order"
+    const bool tile_order_on = order_knob != 0;
     if (tile_order_on && owned > 0) {
         const size_t tb = (size_t)owned * 4;
         if (c->d_tiles.cap < 3 * tb) {
@@ -335,8 +372,7 @@ static int render_impl(hjr_ctx* c, const hjr_params* p, void* d_color, void* d_a
         // Inside a class the tiles can also be ordered by what they cost in the previous frame of the same configuration.  That
         // shortens the tail of a launch further (an 8-GPU share of C2: 19.0 -> 18.4 ms) but gives up the scanline order inside a
         // class, which costs 1.6 % when the launch is long (N = 1: 134.6 -> 136.8 ms): used when the frame is split over several
-        // GPUs.  Pure scheduling: no pixel depends on it.  HJR_TILE_ORDER=1 / 2 force it off / on.
-        static const int order_knob = getenv("HJR_TILE_ORDER") ? atoi(getenv("HJR_TILE_ORDER")) : -1;
+        // GPUs.  Pure scheduling: no pixel depends on it.  Option "tile_order" = 1 / 2 forces it off / on.
         const bool cost_feedback = order_knob == 2 || (order_knob != 1 && world > 1);
         const uint64_t tag = ((uint64_t)p->width << 48) ^ ((uint64_t)p->height << 32) ^ ((uint64_t)p->spp << 12) ^ ((uint64_t)world << 8) ^
                              ((uint64_t)p->rank << 2) ^ (uint64_t)p->integrator ^ 0x8000000000000000ull;

@@ -45,10 +45,11 @@ struct hjr_ctx {
     hjr::SceneCopy scene;
     bool have_scene = false, have_frame = false;
     std::vector<float> last_m, last_inv; // instance transforms of the frame data currently on the device
-    bool last_allow_lds = true;
+    uint32_t last_build_tag = 0; // the build options the current frame data was built with
     hjr::FrameData pending; // built by hjr_prepare_transforms, made current by hjr_commit_transforms
     std::vector<float> pending_m, pending_inv;
-    bool pending_valid = false, pending_same = false, pending_allow_lds = true;
+    bool pending_valid = false, pending_same = false;
+    uint32_t pending_build_tag = 0;
     double pending_build_ms = 0.0;
     hjr::FrameData frame;
     DevBuf d_nodes, d_tri_geom, d_tri_shade, d_tri_inst, d_materials, d_lights, d_lut, d_work;
@@ -66,7 +67,7 @@ struct hjr_ctx {
     DevBuf d_dn_a, d_dn_b, d_dn_out; // denoise ping-pong / host-entry staging
     hjr_stats stats;
     bool event_pending = false;
-    int blocks_per_cu = 0; // 0 = ask the occupancy API
+    hjr::Options opt; // hjr_set_option (host/options.hpp): the library reads no environment variable
 };
 
 
@@ -104,10 +105,9 @@ template <int I, bool S, bool LDS, bool SP, int W, int A> static int launch_wf3(
     if (blocks > max_useful) blocks = max_useful ? max_useful : 1;
     KParams k2 = kp;
     k2.wf_cap = cap;
-    k2.wf_refill = HJR_WF_REFILL; k2.wf_trace_min = HJR_WF_TRACE_MIN; k2.wf_prefetch_min = HJR_WF_PREFETCH_MIN;
-    if (const char* e = getenv("HJR_WF_REFILL")) { int v = atoi(e); if (v >= 1 && v <= 64) k2.wf_refill = (uint32_t)v; }       // tuning knobs
-    if (const char* e = getenv("HJR_WF_PREFETCH_MIN")) { int v = atoi(e); if (v >= 1 && v <= 64) k2.wf_prefetch_min = (uint32_t)v; }
-    if (const char* e = getenv("HJR_WF_TRACE_MIN")) { int v = atoi(e); if (v >= 1 && v <= 4096) k2.wf_trace_min = (uint32_t)v; }
+    k2.wf_refill = (uint32_t)c->opt.get(hjr::OPT_WF_REFILL, HJR_WF_REFILL); // tuning options
+    k2.wf_trace_min = (uint32_t)c->opt.get(hjr::OPT_WF_TRACE_MIN, HJR_WF_TRACE_MIN);
+    k2.wf_prefetch_min = (uint32_t)c->opt.get(hjr::OPT_WF_PREFETCH_MIN, HJR_WF_PREFETCH_MIN);
     const size_t ctx_bytes = (size_t)(HJR_WF_CTX_F4 + (A ? HJR_WF_AOV_F4 : 0)) * 16 * blocks * cap; // context records, then (albedo / normal launches) the AOV sums
     if (c->d_wf_ctx.cap < ctx_bytes) {
         c->d_wf_ctx.release();
@@ -135,10 +135,9 @@ template <int I, bool S, bool LDS, bool SP, int W, int A> static int launch_wf3(
 template <int I, bool S, bool LDS, int W, int A> static int launch_wf2(hjr_ctx* c, const KParams& kp, uint64_t n_items, hipStream_t st)
 {
     uint32_t cap = LDS ? 2048 : 4096; // contexts per workgroup: more of them in flight pay when every node comes from memory (1 M triangles: 272 -> 259 ms)
-    if (const char* e = getenv("HJR_WF_CAP")) { int v = atoi(e); if (v >= 64 && v <= 32768 && (v & (v - 1)) == 0) cap = (uint32_t)v; }
-    uint32_t short_stack = HJR_SHORT_STACK;
-    const bool force_short = getenv("HJR_SHORT_STACK") != nullptr;
-    if (force_short) { int v = atoi(getenv("HJR_SHORT_STACK")); if (v >= 1 && v <= 64) short_stack = (uint32_t)v; }
+    { const int v = c->opt.get(hjr::OPT_WF_CAP, (int)cap); if ((v & (v - 1)) == 0) cap = (uint32_t)v; }
+    const bool force_short = c->opt.is_set(hjr::OPT_SHORT_STACK);
+    const uint32_t short_stack = (uint32_t)c->opt.get(hjr::OPT_SHORT_STACK, HJR_SHORT_STACK);
     const size_t scene_bytes = LDS ? ((size_t)kp.n_node_f4 + kp.n_tri_f4 + kp.n_mat_f4 + kp.n_light_f4) * 16 : 0;
     const size_t fixed = scene_bytes + 96 + (size_t)HJR_WF_QUEUES * cap * 2;
     const size_t lds_max = 160u * 1024u;
@@ -180,25 +179,22 @@ template <int I, bool S> static int launch_wf(hjr_ctx* c, const KParams& kp, uin
 template <int I, bool S> int hjr_launch(hjr_ctx* c, const KParams& kp_in, uint64_t n_items, int lds_mode, hipStream_t st)
 {
     KParams kp = kp_in;
-    const char* nm_env = getenv("HJR_NODE_MIN"); // tuning knob
-    const uint32_t nm_forced = nm_env && atoi(nm_env) >= 1 && atoi(nm_env) <= 64 ? (uint32_t)atoi(nm_env) : 0u;
+    const uint32_t nm_forced = (uint32_t)c->opt.get(hjr::OPT_NODE_MIN, 0); // option "node_min"
     // Two kernel families produce the same bits (hjr_kernel.hip.h / hjr_wavefront.hip.h); which one is faster depends on the launch
     // (MI355X, profiles/r02_experiments.md §4).  Bundled scene (LDS-resident), 1080p x 256 spp: MIS 193 ms wavefront vs 234 ms megakernel
     // (the NEE shadow ray and the next closest-hit ray of its bounce are traced by sorted, full waves), NEE colour-only 126.7 vs 126.6,
     // NEE with albedo / normal AOVs 145.7 vs 128.9, Pathtrace 104.7 vs 91.2.  Scenes read from memory (1 M triangles, 1080p x 64 spp):
-    // MIS 416 vs 635 ms, NEE 188 vs 179.  So: MIS -> wavefront kernel, everything else -> megakernel.  HJR_PIPELINE=mega | wf overrides.
-    const char* pe = getenv("HJR_PIPELINE");
+    // MIS 416 vs 635 ms, NEE 188 vs 179.  So: MIS -> wavefront kernel, everything else -> megakernel.  option "pipeline" overrides.
+    const int pe = c->opt.get(hjr::OPT_PIPELINE, 0); // option "pipeline": 1 megakernel, 2 wavefront kernel
     const bool lds_layout = lds_mode == 1 || lds_mode == 2;
     bool wf = I == HJR_INTEGRATOR_MIS;
-    if (pe && strcmp(pe, "wf") == 0) wf = true;
-    if (pe && strcmp(pe, "mega") == 0) wf = false;
+    if (pe == 2) wf = true;
+    if (pe == 1) wf = false;
     // the wavefront kernel's queue positions are free-running 32-bit counters per workgroup (hjr_wavefront.hip.h::WfShared): a context is
     // queued at most ~12 times per sample; frames that could bring one workgroup near 2^32 pushes (4x its even share) stay with the megakernel
     if ((double)n_items * kp.chunk_spp * 12.0 * 4.0 / (double)(c->n_cus > 0 ? c->n_cus : 1) >= 4.0e9) wf = false;
     c->stats.pipeline = wf ? 1u : 0u;
-    kp.hold_min = HJR_HOLD_MIN; kp.hold_age = HJR_HOLD_AGE;
-    if (const char* e = getenv("HJR_HOLD_MIN")) { int v = atoi(e); if (v >= 0 && v <= 64) kp.hold_min = (uint32_t)v; } // tuning knobs
-    if (const char* e = getenv("HJR_HOLD_AGE")) { int v = atoi(e); if (v >= 1 && v <= 1000) kp.hold_age = (uint32_t)v; }
+    kp.hold_min = (uint32_t)c->opt.get(hjr::OPT_HOLD_MIN, HJR_HOLD_MIN); kp.hold_age = (uint32_t)c->opt.get(hjr::OPT_HOLD_AGE, HJR_HOLD_AGE); // tuning options
     kp.node_min = nm_forced ? nm_forced : (lds_layout ? (wf ? HJR_NODE_MIN_LDS_WF : HJR_NODE_MIN_LDS) : HJR_NODE_MIN_MEM);
 #ifdef HJR_LEAN_VARIANT /* kernel experiments (make variant X="-DHJR_LEAN_VARIANT ..."): only the LDS-resident megakernel is instantiated: builds in seconds */
     c->stats.pipeline = 0u;
@@ -224,13 +220,12 @@ template <int I, bool S, int W> static int launch_mem(hjr_ctx* c, const KParams&
 }
 template <int I, bool S, int W, int A> static int launch_mem2(hjr_ctx* c, const KParams& kp, uint64_t n_items, hipStream_t st)
 {
-    uint32_t short_stack = HJR_SHORT_STACK;
-    if (const char* e = getenv("HJR_SHORT_STACK")) { int v = atoi(e); if (v >= 1 && v <= 64) short_stack = (uint32_t)v; } // tests force the overflow path with 2
+    const uint32_t short_stack = (uint32_t)c->opt.get(hjr::OPT_SHORT_STACK, HJR_SHORT_STACK); // tests force the overflow path with 2
     const uint32_t lds_entries = kp.stack_depth < short_stack ? kp.stack_depth : short_stack;
     const size_t smem = (size_t)HJR_BLOCK * lds_entries * 4;
     auto kern = hjr_render_kernel<I, S, HJR_BLOCK, false, false, W, A>;
     int per_cu = 0;
-    if (c->blocks_per_cu > 0) per_cu = c->blocks_per_cu;
+    if (c->opt.is_set(hjr::OPT_BLOCKS_PER_CU)) per_cu = c->opt.get(hjr::OPT_BLOCKS_PER_CU, 0);
     else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, HJR_BLOCK, smem) != hipSuccess || per_cu < 1)
         per_cu = 2;
     uint64_t blocks = (uint64_t)c->n_cus * (uint64_t)per_cu;

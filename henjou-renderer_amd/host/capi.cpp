@@ -278,7 +278,7 @@ extern "C" int hjr_render_file(const char* render_option_json, int device)
     // Output stage off the critical path: float4 -> sRGB8 -> PNG -> file runs on a writer thread while the main thread
     // already builds and renders the next frame (two frame buffers in rotation).  The reference's loop is serial
     // (renderer.h:1281-1302); the files are the same.  Only aov_color is produced: Default mode never reads the albedo /
-    // normal AOVs (they feed the OptiX denoiser, denoiser.h:94-97).  HJR_SERIAL_IO=1 disables the overlap.
+    // normal AOVs (they feed the OptiX denoiser, denoiser.h:94-97).  "Henjou_HIP": {"serial_io": true} disables the overlap.
     struct Slot { std::vector<float> color; std::string name; bool full = false; };
     Slot slots[2];
     for (Slot& sl : slots) sl.color.resize(npx * 4);
@@ -287,7 +287,7 @@ extern "C" int hjr_render_file(const char* render_option_json, int device)
     bool quit = false;
     int write_rc = HJR_OK;
     std::string write_err;
-    const bool serial_io = getenv("HJR_SERIAL_IO") && atoi(getenv("HJR_SERIAL_IO")) != 0;
+    const bool serial_io = opt.serial_io != 0;
     auto write_slot = [&](Slot& sl) -> int {
         std::vector<uint8_t> rgba8(npx * 4);
         hjr::float4_to_srgb8(sl.color.data(), rgba8.data(), (uint32_t)npx);

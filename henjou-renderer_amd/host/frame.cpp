@@ -64,11 +64,13 @@ namespace {
 
 // Host worker threads for the per-frame scene preparation (flatten, BVH build, emit).  Every parallel loop below is either
 // element-wise or merges per-chunk partial results that are exact (min / max / integer counts), so the emitted arrays do not
-// depend on the thread count.  HJR_HOST_THREADS overrides the default min(hardware threads, 16).
+// depend on the thread count.  Default min(hardware threads, 16); hjr::set_host_threads (option "host_threads") overrides it process-wide.
+std::atomic<int> g_host_threads{ 0 };
 inline unsigned host_threads()
 {
+    const int forced = g_host_threads.load(std::memory_order_relaxed);
+    if (forced >= 1) return (unsigned)std::min(forced, 256);
     static const unsigned n = [] {
-        if (const char* e = getenv("HJR_HOST_THREADS")) { int v = atoi(e); if (v >= 1) return (unsigned)std::min(v, 256); }
         unsigned h = std::thread::hardware_concurrency();
         return h == 0 ? 1u : std::min(h, 16u);
     }();
@@ -239,11 +241,11 @@ struct Builder {
     // Whole tree.  Scenes below `par_min` triangles: the plain recursion.  Above: the top of the tree is built by this thread
     // (its big nodes with parallel passes), the subtrees by worker threads; sub-results are spliced in task order, so the node
     // array (and everything emitted from it) is the same for any number of threads.
+    bool timing = false; // stage times on stderr
     void build_all(uint32_t n, uint32_t par_min = 65536u, uint32_t task_size = 32768u)
     {
         nodes.reserve((size_t)2 * n);
         if (n < par_min) { build(0, n, 0); return; }
-        const bool timing = getenv("HJR_BUILD_TIMING") != nullptr;
         auto t0 = std::chrono::steady_clock::now();
         defer_below = task_size;
         build(0, n, 0);
@@ -384,11 +386,14 @@ void emit_bvh4(const Builder& B, FrameData& out)
 
 } // namespace
 
-bool build_frame(const SceneCopy& sc, const float* M, const float* Mi, uint32_t n_inst, bool allow_lds, FrameData& out, std::string& err)
+void set_host_threads(int n) { g_host_threads.store(n > 0 ? n : 0, std::memory_order_relaxed); }
+
+bool build_frame(const SceneCopy& sc, const float* M, const float* Mi, uint32_t n_inst, const BuildOptions& bo, FrameData& out, std::string& err)
 {
+    const bool allow_lds = bo.allow_lds;
     if (n_inst != sc.n_instances) { err = "instance count does not match the uploaded scene"; return false; }
     const uint32_t n = sc.n_triangles;
-    const bool timing = getenv("HJR_BUILD_TIMING") != nullptr; // stage times on stderr
+    const bool timing = bo.timing; // stage times on stderr
     auto t_last = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) {
         if (!timing) return;
@@ -461,7 +466,8 @@ bool build_frame(const SceneCopy& sc, const float* M, const float* Mi, uint32_t 
 
     // BVH over padded triangle boxes
     Builder B;
-    if (const char* e = getenv("HJR_LEAF_MAX")) { int v = atoi(e); if (v >= 1 && v <= (int)HJR_LEAF_MAX) B.leaf_max = (uint32_t)v; } // tuning knob
+    if (bo.leaf_max >= 1 && bo.leaf_max <= (int)HJR_LEAF_MAX) B.leaf_max = (uint32_t)bo.leaf_max; // option "leaf_max"
+    B.timing = timing;
     std::vector<Box> tbox(n);
     std::vector<float> cent((size_t)n * 3);
     std::vector<uint32_t> order(n);
@@ -531,13 +537,13 @@ bool build_frame(const SceneCopy& sc, const float* M, const float* Mi, uint32_t 
     if (allow_lds) {
         // 16-bit stack entries hold leaves of at most 3 triangles below triangle 8192 and node ids below 32768 (hjr_traverse.hip.h)
         const bool fits16 = (size_t)HJR_BLOCK_LDS * stack2 * 2 + 16 + bvh2_bytes + table_bytes <= HJR_LDS_BUDGET && n_inner2 < 32768u && n < 8192u && B.leaf_max <= 3u;
-        const bool prefer16 = getenv("HJR_LDS_STACK16") && atoi(getenv("HJR_LDS_STACK16")) != 0; // test / tuning knob: 16-bit entries whenever they fit
+        const bool prefer16 = bo.prefer_stack16; // option "lds_stack16": 16-bit entries whenever they fit
         if (fits16 && prefer16) lds_mode = 2;
         else if ((size_t)HJR_BLOCK_LDS * stack2 * 4 + 16 + bvh2_bytes + table_bytes <= HJR_LDS_BUDGET) lds_mode = 1;
         else if (fits16) lds_mode = 2;
     }
-    if (const char* e = getenv("HJR_BVH_WIDTH")) { // tuning knob: force a node format (forcing 4 also forces the memory path)
-        int v = atoi(e);
+    if (bo.bvh_width == 2 || bo.bvh_width == 4) { // option "bvh_width": force a node format (forcing 4 also forces the memory path)
+        const int v = bo.bvh_width;
         if (v == 4) lds_mode = 0;
         out.width = (v == 2 || (v != 4 && lds_mode)) ? 2u : 4u;
     } else out.width = lds_mode ? 2u : 4u;

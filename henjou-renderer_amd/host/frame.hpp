@@ -9,6 +9,7 @@
 
 #include "../../include/henjou_hip.h"
 #include "../csrc/hjr_layout.h"
+#include "options.hpp"
 
 namespace hjr {
 
@@ -36,8 +37,8 @@ struct SceneCopy {
     bool set(const hjr_scene_view& v, std::string& err);
 };
 
-// allow_lds: let small scenes use the LDS-resident BVH2 layout
-bool build_frame(const SceneCopy& sc, const float* transforms12, const float* inv12, uint32_t n_instances, bool allow_lds,
+// bo.allow_lds: let small scenes use the LDS-resident BVH2 layout; the other fields force a layout / leaf size (tests, tuning)
+bool build_frame(const SceneCopy& sc, const float* transforms12, const float* inv12, uint32_t n_instances, const BuildOptions& bo,
                  FrameData& out, std::string& err);
 
 } // namespace hjr

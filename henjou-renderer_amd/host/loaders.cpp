@@ -125,6 +125,11 @@ bool load_render_option(const std::string& path, hjr_render_option& o, std::stri
             if (tl != 8) throw JsonError("Henjou_HIP.tile: only 8 (8x8 pixel tiles) is supported");
             o.devices = (uint32_t)dv;
             o.tile = 8;
+            // serial_io: hjr_render_file without the overlap of the output stage / the next frame's host preparation with the render;
+            // fast_math: the approximate-arithmetic kernels (HJR_FLAG_FAST_MATH; pictures within the metric's RMSE tolerance, not bit-exact)
+            auto flag = [&](const char* k) { const Json* v = h->find(k); return v ? (v->is_bool() ? v->as_bool() : v->as_number() != 0.0) : false; };
+            o.serial_io = flag("serial_io") ? 1 : 0;
+            o.fast_math = flag("fast_math") ? 1 : 0;
         }
     } catch (std::exception& e) { // :222-225
         err = std::string("Caught exception: ") + e.what();

@@ -133,6 +133,8 @@ typedef struct hjr_render_option {
     int32_t integrator;          /* default HJR_INTEGRATOR_NEE */
     uint32_t devices;            /* default 1: GPUs of the node that share each frame (pixel-tile shard, one process per GPU) */
     uint32_t tile;               /* shard granularity in pixels; 8 is the only supported value */
+    int32_t serial_io;           /* default 0; 1: hjr_render_file renders, writes and prepares the next frame one after the other (no overlap) */
+    int32_t fast_math;           /* default 0; 1: hjr_render_file / henjou_cli launch with HJR_FLAG_FAST_MATH */
 } hjr_render_option;
 
 typedef struct hjr_camera {      /* Params.camera_* (renderer/renderer.h:1187-1191) */
@@ -256,6 +258,30 @@ int hjr_render_denoised(hjr_ctx*, const hjr_params*, int render_mode, float* out
 int hjr_denoise_device(hjr_ctx*, int render_mode, uint32_t in_w, uint32_t in_h, const void* d_color, const void* d_albedo,
                        const void* d_normal, void* d_out, uint32_t out_w, uint32_t out_h, void* hip_stream);
 int hjr_get_stats(hjr_ctx*, hjr_stats* out);
+/* Tuning / test options of a context.  The library reads NO environment variable: kernel selection and layouts depend on the scene, the
+ * launch parameters and these options only.  value -1 = the library's default; HJR_ERR_ARG for an unknown key or a value out of range.
+ *   key               values      meaning (default)
+ *   "pipeline"        0 1 2       kernel family: 0 per launch what was measured faster (wavefront kernels for MIS, megakernel otherwise; default),
+ *                                 1 persistent megakernel, 2 workgroup-local wavefront kernel
+ *   "lds_bvh"         0 1         1: stage BVH2 + triangles in LDS when they fit (default), 0: always read the scene from memory     [*]
+ *   "lds_stack16"     0 1         1: 16-bit LDS traversal-stack entries whenever the tree admits them (default: only when 32-bit ones do not fit) [*]
+ *   "bvh_width"       2 4         force the node format; 4 also forces the memory path (default: BVH2 in LDS when it fits, BVH4 otherwise)   [*]
+ *   "leaf_max"        1..4        triangles per BVH leaf (2)                                                                        [*]
+ *   "node_min"        1..64       traversal descent loops: lanes still descending below which a pass moves on to the leaves (4 / 8 / 24 by layout and family)
+ *   "hold_min"        0..64       megakernel, LDS layouts: metallic hits a wave collects before it shades them; 0 never holds (8)
+ *   "hold_age"        1..1000     ... or rounds the oldest of them has waited (2)
+ *   "short_stack"     1..64       memory layouts: traversal-stack entries per lane kept in LDS, deeper ones overflow to HBM (16)
+ *   "blocks_per_cu"   1..8        memory layouts: workgroups per CU of the persistent grid (occupancy query)
+ *   "tile_order"      0 1 2       0 plain tile order, 1 first-hit classes, 2 classes + measured cost of the previous frame (1 on one GPU, 2 when sharded)
+ *   "wf_cap"          64..32768   wavefront kernel: path contexts per workgroup, a power of two (2048 in LDS layouts, 4096 otherwise)
+ *   "wf_refill" / "wf_prefetch_min" / "wf_trace_min"   wavefront kernel: hand-over thresholds of the trace stage, scheduler preference
+ *   "host_threads"    1..256      worker threads of the per-frame host preparation, process-wide (min(hardware threads, 16))
+ *   "verbose"         0 1         BVH format, sizes, host build stages per frame on stderr (0)
+ *   "force_rebuild"   0 1         rebuild the frame data even when the transforms did not change (0)
+ *   [*] takes effect at the next hjr_set_transforms / hjr_prepare_transforms.
+ * No reference counterpart (OptiX owns these decisions); tests use them to force every kernel layout. */
+int hjr_set_option(hjr_ctx*, const char* key, int value);
+int hjr_get_option(hjr_ctx*, const char* key, int* value);
 /* Host-only self-test of the 16-bit traversal-stack encoding (csrc/hjr_traverse.hip.h): 0 when every child ref of a tree the
  * builder admits to that layout survives encode + decode.  No reference counterpart (OptiX owns its traversal stack). */
 int hjr_selftest_stack16(void);

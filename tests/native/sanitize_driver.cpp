@@ -54,7 +54,7 @@ int main(int argc, char** argv)
     }
 
     hjr_scene_view v;
-    memset(&v, 0, sizeof(v));
+    HJR_INIT(v);
     v.n_vertices = (uint32_t)sc.vertices.size(); v.n_triangles = (uint32_t)sc.indices.size() / 3; v.n_instances = ninst;
     v.n_materials = (uint32_t)sc.materials.size(); v.n_lights = (uint32_t)sc.light_prim_ids.size();
     v.vertices = &sc.vertices[0].x; v.normals = &sc.normals[0].x; v.texcoords = &sc.texcoords[0].x;
@@ -66,7 +66,9 @@ int main(int argc, char** argv)
     CHECK(copy.set(v, err));
     for (int allow_lds = 0; allow_lds < 2; allow_lds++) {
         hjr::FrameData fd;
-        CHECK(hjr::build_frame(copy, m.data(), inv.data(), ninst, allow_lds != 0, fd, err));
+        hjr::BuildOptions bo;
+        bo.allow_lds = allow_lds != 0;
+        CHECK(hjr::build_frame(copy, m.data(), inv.data(), ninst, bo, fd, err));
         CHECK(fd.n_tris == v.n_triangles && fd.n_nodes > 0 && fd.stack_need >= 2);
         CHECK(fd.width == (allow_lds ? 2u : 4u));
     }

@@ -15,6 +15,27 @@ def f32_time(frame, fps):
     return float(np.float32(frame) / np.float32(fps))
 
 
+DEVICE_OPTIONS = {}  # options every Cornell.device() applies (tests force kernel layouts / families with them)
+
+
+class device_options:
+    """with device_options(lds_bvh=0, pipeline="wf"): ...  — hjr_set_option values for the devices created inside (the library reads no
+    environment variable).  pipeline takes "mega" / "wf" or the numbers 1 / 2."""
+
+    def __init__(self, **kv):
+        self.kv = {k: ({"mega": 1, "wf": 2}.get(v, v) if k == "pipeline" else v) for k, v in kv.items()}
+
+    def __enter__(self):
+        self.old = dict(DEVICE_OPTIONS)
+        DEVICE_OPTIONS.update(self.kv)
+        return self
+
+    def __exit__(self, *a):
+        DEVICE_OPTIONS.clear()
+        DEVICE_OPTIONS.update(self.old)
+        return False
+
+
 class Cornell:
     """cornelbox.gltf loaded via libhenjou_hip.so's scene surface, at frame 1 (t = 1/24 s)."""
 
@@ -43,8 +64,12 @@ class Cornell:
         kw.setdefault("ibl_intensity", self.opt.IBL_intensity)
         return ob.make_params(w, h, spp, self.camera.as_dict(), **kw)
 
-    def device(self):
+    def device(self, options=None):
+        """A device context with this scene resident.  `options` (and the module-wide DEVICE_OPTIONS the `device_options` context manager
+        sets) go through hjr_set_option BEFORE the frame data is built, so that layout options act on it."""
         d = hjr.Device(0)
+        for k, v in dict(DEVICE_OPTIONS, **(options or {})).items():
+            d.set_option(k, v)
         d.upload_scene(self.scene.view)
         d.set_transforms(self.arrays["transforms"], self.arrays["inv_transforms"])
         return d

@@ -145,3 +145,10 @@ def test_tonemappers_match_oracle_and_formulae():
     assert np.all(np.diff(ys) >= -1e-6)
     with pytest.raises(hjr.HjrError):
         hjr.tonemap_to_srgb8(px, 7)
+
+
+def test_library_reads_no_environment_variable():
+    """The shipped library's behaviour depends on its arguments and hjr_set_option only: no getenv in its dynamic symbol table
+    (round 2 read ~15 tuning knobs from the caller's environment inside the launch path)."""
+    out = os.popen("nm -D --undefined-only %s" % hjr.LIB_PATH).read()
+    assert "getenv" not in out, [l for l in out.splitlines() if "getenv" in l]

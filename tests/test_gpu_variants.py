@@ -3,18 +3,17 @@
 hjr_launch.hip.h::hjr_launch dispatches four layouts (hjr_stats.lds_mode): 0 = BVH4 read from memory, 1 = BVH2 staged in LDS with
 32-bit stack entries, 2 = BVH2 in LDS with 16-bit stack entries, 3 = BVH2 read from memory; the memory-path layouts keep the
 top of a lane's traversal stack in LDS and overflow into an HBM buffer.  The bundled scene only ever selects layout 1, so each
-other layout is forced here (the host-side knobs are read when the frame data is built / the kernel is launched) and checked,
+other layout is forced here (hjr_set_option: layout options act when the frame data is built, the others at the launch) and checked,
 for NEE / Pathtrace / MIS with and without the albedo / normal AOVs, against the oracle's PORTABLE mode: same bar as
 test_gpu_parity.py.  The layout actually used and the overflow activity are asserted through hjr_stats.
 """
-import contextlib
 import os
 
 import numpy as np
 import pytest
 
 import oracle_binding as ob
-from scene_util import Cornell, StressScene, hjr
+from scene_util import Cornell, StressScene, device_options, hjr
 from test_gpu_parity import assert_bitexact
 
 pytestmark = pytest.mark.gpu
@@ -22,18 +21,10 @@ pytestmark = pytest.mark.gpu
 ALL_INTEGRATORS = (hjr.INTEGRATOR_NEE, hjr.INTEGRATOR_PT, hjr.INTEGRATOR_MIS)
 
 
-@contextlib.contextmanager
 def knobs(**kv):
-    old = {k: os.environ.get(k) for k in kv}
-    os.environ.update({k: str(v) for k, v in kv.items()})
-    try:
-        yield
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+    """Options for the devices created inside the `with` block, spelled like the environment variables rounds 1 - 2 used
+    (HJR_LDS_BVH=0 -> hjr_set_option("lds_bvh", 0)); the library itself reads no environment any more."""
+    return device_options(**{k[4:].lower(): v for k, v in kv.items()})
 
 
 _oracle_cache = {}
@@ -55,7 +46,7 @@ def check_layout(scene, key, env, expect_mode, w=96, h=64, spp=4, integrators=AL
     if pipeline is not None:  # None = let the library choose the kernel family (test_pipeline_selection)
         env["HJR_PIPELINE"] = pipeline
     with knobs(**env):
-        d = scene.device()  # host/frame.cpp reads the layout knobs here; the launch reads HJR_SHORT_STACK
+        d = scene.device()  # the options are set on the new context before its frame data is built
         try:
             for integ in integrators:
                 oc, oa, on = oracle_frame(scene, key, w, h, spp, integ)
@@ -227,8 +218,7 @@ def test_full_size_frames_agree_between_the_families(cornell):
 def test_pipeline_selection(cornell):
     """Without HJR_PIPELINE the library picks the kernel family per launch (hjr_launch.hip.h::hjr_launch): the wavefront kernels for MIS
     (any layout), the megakernel otherwise.  Whatever it picks, the bits are the oracle's."""
-    old = os.environ.pop("HJR_PIPELINE", None)
-    try:
+    if True:
         d = cornell.device()
         try:
             def pipe(integ, aovs):
@@ -249,6 +239,33 @@ def test_pipeline_selection(cornell):
                 assert d.stats()["pipeline"] == 1  # ... MIS is faster on the wavefront kernels in every layout
             finally:
                 d.close()
+
+
+def test_option_api_validates_keys_and_ranges(cornell):
+    d = cornell.device()
+    try:
+        assert d.get_option("pipeline") == -1 and d.get_option("node_min") == -1  # defaults
+        d.set_option("node_min", 7)
+        assert d.get_option("node_min") == 7
+        d.set_option("node_min", -1)
+        assert d.get_option("node_min") == -1
+        for key, bad in (("no_such_option", 1), ("node_min", 0), ("node_min", 65), ("bvh_width", 3), ("wf_cap", 100), ("pipeline", 3), ("leaf_max", 5)):
+            with pytest.raises(hjr.HjrError):
+                d.set_option(key, bad)
+        with pytest.raises(hjr.HjrError):
+            d.get_option("no_such_option")
+        # a layout option acts at the next set_transforms: the same context goes from the LDS layout to BVH4 from memory and back
+        p = cornell.hjr_params(48, 32, 2)
+        a, _, _ = d.render(p, want_aovs=False)
+        assert d.stats()["lds_mode"] == 1
+        d.set_option("lds_bvh", 0)
+        d.set_transforms(cornell.arrays["transforms"], cornell.arrays["inv_transforms"])
+        b, _, _ = d.render(p, want_aovs=False)
+        assert d.stats()["lds_mode"] == 0
+        assert_bitexact(a, b, "LDS layout vs memory layout on one context")
+        d.set_option("lds_bvh", -1)
+        d.set_transforms(cornell.arrays["transforms"], cornell.arrays["inv_transforms"])
+        d.render(p, want_aovs=False)
+        assert d.stats()["lds_mode"] == 1
     finally:
-        if old is not None:
-            os.environ["HJR_PIPELINE"] = old
+        d.close()

@@ -19,8 +19,7 @@ def test_frame_build_is_thread_count_invariant(tmp_path):
                           stdout=subprocess.DEVNULL)
     lines = {}
     for threads in ("1", "3", "8"):
-        env = dict(os.environ, HJR_HOST_THREADS=threads)
-        out = subprocess.run([exe, sdir, "render_option_stress.json", "1"], env=env, capture_output=True, text=True, timeout=300)
+        out = subprocess.run([exe, sdir, "render_option_stress.json", "1", threads], capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, out.stderr
         m = re.search(r"\((\d+) tris, (\d+) nodes, width (\d+), depth (\d+), stack (\d+), lds_mode (\d+)\)\s+hash ([0-9a-f]+)", out.stdout)
         assert m, out.stdout

@@ -17,6 +17,9 @@ int main(int argc, char** argv)
     if (argc < 3) return 2;
     const std::string dir = argv[1], config = argv[2];
     const int reps = argc > 3 ? atoi(argv[3]) : 3;
+    if (argc > 4) hjr::set_host_threads(atoi(argv[4])); // worker threads (default min(hardware threads, 16))
+    hjr::BuildOptions bo;
+    bo.timing = argc > 5 && atoi(argv[5]) != 0;          // stage times on stderr
     std::string err;
     hjr_render_option opt;
     HJR_INIT(opt);
@@ -27,7 +30,7 @@ int main(int argc, char** argv)
     std::vector<float> m(ninst * 12), inv(ninst * 12);
     hjr::eval_transforms(sc, 1.0f / 24.0f, m.data(), inv.data());
     hjr_scene_view v;
-    memset(&v, 0, sizeof(v));
+    HJR_INIT(v);
     v.n_vertices = (uint32_t)sc.vertices.size(); v.n_triangles = (uint32_t)sc.indices.size() / 3; v.n_instances = ninst;
     v.n_materials = (uint32_t)sc.materials.size(); v.n_lights = (uint32_t)sc.light_prim_ids.size();
     v.vertices = &sc.vertices[0].x; v.normals = &sc.normals[0].x; v.texcoords = &sc.texcoords[0].x;
@@ -39,7 +42,7 @@ int main(int argc, char** argv)
     for (int r = 0; r < reps; r++) {
         hjr::FrameData fd;
         auto t0 = std::chrono::steady_clock::now();
-        if (!hjr::build_frame(copy, m.data(), inv.data(), ninst, true, fd, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
+        if (!hjr::build_frame(copy, m.data(), inv.data(), ninst, bo, fd, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
         double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         unsigned long long h = 1469598103934665603ull; // FNV-1a over the emitted arrays: the build must not depend on threads
         auto mix = [&](const void* p, size_t n) { const unsigned char* b = (const unsigned char*)p; for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; } };

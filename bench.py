@@ -18,8 +18,11 @@ performs (colour + albedo + normal AOVs, renderer/renderer.h:1222-1224); `color_
 instantiation next to it.  Plus
   "roofline":     the bound is chosen per launch from hardware counters collected IN THIS RUN (rocprofv3 --pmc passes over
                   tools/kbench, the same library and workload, started before this process touches the GPU):
-                    * "valu": useful fp32 VALU lane operations (wave instructions x average active lanes, x 2 FLOP) per second
-                      against the 157.3 TFLOP/s vector peak of MI355X_MICROARCH.md;
+                    * "valu": VALU lane-slot utilisation in the peak's units: every VALU wave instruction x its active lanes counted as
+                      one 2-FLOP operation per second, against the 157.3 TFLOP/s vector peak of MI355X_MICROARCH.md (= 64 lanes x every
+                      issue slot x 2).  It is an UPPER bound on the useful-FLOP fraction: moves, compares, integer and address
+                      arithmetic count like an fma.  `roofline.flops` next to it counts only the fp32 arithmetic instructions
+                      (SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F32; an fma = 2 FLOP) against the same peak;
                     * "hbm": the COUNTER bytes (FETCH_SIZE x 2 + WRITE_SIZE, Infinity-Cache hits included) against 8 TB/s;
                   whichever fraction is larger is the roof the launch is closer to and becomes `bound` / `frac` (both <= 1 by
                   construction, both reported under `counters`).
@@ -55,6 +58,8 @@ PMC_PASSES = [  # separate passes: SQ has 8 slots, FETCH_SIZE / WRITE_SIZE do no
     ["FETCH_SIZE"],
     ["WRITE_SIZE"],
 ]
+PMC_FLOP_PASS = ["SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_CVT",
+                 "SQ_INSTS_SALU", "SQ_INSTS_LDS"]
 
 
 def collect_pmc(kbench_args, env=None, timeout=150, passes=None):
@@ -124,10 +129,25 @@ def stress_secondary(lib_path, spheres, segments, env=None):
     c = collect_pmc([lib_path, cfg, "--reps", "1"], env=env, timeout=300, passes=[["FETCH_SIZE"], ["WRITE_SIZE"]])
     traffic = c["FETCH_SIZE"] * 1024.0 * 2.0 + c["WRITE_SIZE"] * 1024.0
     gbps = traffic / (ms * 1e-3) / 1e9
+    # what the algorithm has to touch: the counting variant's own box / triangle / hit / light-sample counts at 1/8 of the samples, priced with
+    # the byte sizes of THIS library's records (hjr_layout.h: 64-byte compressed BVH4 node per 4 box tests, 48-byte triangle, 64 + 80-byte
+    # shading + material record per shaded hit, 96-byte light record per light sample, 16 bytes of output per pixel)
+    algorithmic = None
+    rs = subprocess.run([kb, lib_path, cfg, "--reps", "1", "--stats", "--spp", str(max(spp // 8, 1))], cwd=os.path.join(ROOT, "henjou-renderer_amd", "assets"), env=e,
+                        capture_output=True, text=True, timeout=300)
+    ms_ = re.search(r"samples (\d+) closest (\d+) shadow (\d+) box_c (\d+) tri_c (\d+) box_s (\d+) tri_s (\d+) hits (\d+) lights (\d+)", rs.stdout)
+    if rs.returncode == 0 and ms_:
+        n, _, _, bc, tc, bs_, ts, hits, lights = [float(v) for v in ms_.groups()]
+        per_sample = ((bc + bs_) / 4.0 * 64.0 + (tc + ts) * 48.0 + hits * 144.0 + lights * 96.0) / n + 16.0 / spp
+        alg_bytes = per_sample * w * h * spp
+        algorithmic = {"bytes_per_sample": round(per_sample, 1), "bytes_per_launch": int(alg_bytes), "traffic_over_algorithmic": round(traffic / alg_bytes, 3),
+                       "per_sample": {"box_tests": round((bc + bs_) / n, 2), "tri_tests": round((tc + ts) / n, 2), "shaded_hits": round(hits / n, 3), "light_samples": round(lights / n, 3)},
+                       "note": "record bytes the traversal and shading must read per sample (every visit counted, no cache reuse): counter bytes below it mean L2 reuse"}
     return {"workload": "generated stress scene (%d spheres x %d segments): %dx%d %d spp, NEE, colour only" % (spheres, segments, w, h, spp),
             "triangles": int(tri.group(1)) if tri else None, "value": round(w * h * spp / (ms * 1e3), 3), "unit": "Msamples/s", "kernel_ms_avg": round(ms, 3),
             "roofline": {"bound": "hbm", "achieved": round(gbps, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBS, 5), "traffic": int(traffic),
-                         "definition": "(FETCH_SIZE x 2 + WRITE_SIZE) counter bytes per launch / kernel time: fabric-side traffic, the scene (~100 MB) is Infinity-Cache resident"}}
+                         "algorithmic": algorithmic,
+                         "definition": "(FETCH_SIZE x 2 + WRITE_SIZE) counter bytes per launch / kernel time: fabric-side traffic, the scene (~70 MB) is Infinity-Cache resident"}}
 
 
 def main():
@@ -190,6 +210,10 @@ def main():
             penv = {k: v for k, v in penv.items() if v}
             pmc_full = collect_pmc(kargs + ["--aovs"], env=penv)
             pmc = collect_pmc(kargs, env=penv)
+            try:  # instruction classes of the headline launch (one more pass; its absence only drops the `flops` block)
+                pmc_full.update(collect_pmc(kargs + ["--aovs"], env=penv, passes=[PMC_FLOP_PASS]))
+            except Exception as ex:
+                pmc_full["flop_pass_error"] = "%s: %s" % (type(ex).__name__, ex)
         except Exception as ex:  # reported on the line; never silently replaced by a committed file
             pmc_error = "%s: %s" % (type(ex).__name__, ex)
     secondary = None
@@ -300,7 +324,22 @@ def main():
         return el, ms, {0: "persistent megakernel", 1: "workgroup-local wavefront kernel"}[r.device.stats()["pipeline"]]
 
     elapsed_color, kernel_ms_color, pipe_color = timed(step_color)
+    # opt-in approximate-arithmetic kernels (HJR_FLAG_FAST_MATH; megakernel family): a named side block, never the headline
+    fast_block = None
+    if world == 1:
+        params_exact = params
+        params, _ = r.frame_params(frame, rank=rank, world_size=world, flags=hjr.FLAG_FAST_MATH)
+        elapsed_fast, kernel_ms_fast, _ = timed(step_full)
+        fast_frame = fb.clone()
+        params = params_exact
     elapsed, kernel_ms, pipe_full = timed(step_full)  # the headline: EXACTLY args.steps steps between the fences
+    if world == 1:
+        d2 = (fast_frame[..., :3].double() - fb[..., :3].double()) ** 2
+        fast_block = {"value": round(float(W) * H * SPP * args.steps / elapsed_fast / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(elapsed_fast / args.steps * 1e3, 3),
+                      "kernel_ms_avg": round(sum(kernel_ms_fast) / len(kernel_ms_fast), 3),
+                      "rmse_vs_exact_kernel": {"value": float(torch.sqrt(d2.mean()).item()), "spp": SPP, "pixels": W * H},
+                      "note": "HJR_FLAG_FAST_MATH, 3 AOVs: hardware reciprocal / sqrt / sin / cos / pow and fused multiply-adds in the shading code (the reference's own "
+                              "build is nvcc --use_fast_math); not bit-exact; per-pixel RMSE < 1e-3 at 1024 spp vs the LIBM oracle is tests/test_gpu_fast_math.py"}
 
     total_samples = float(W) * H * SPP * args.steps
     value = total_samples / elapsed / 1e6
@@ -316,6 +355,7 @@ def main():
         "color_only": {"value": round(total_samples / elapsed_color / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(elapsed_color / args.steps * 1e3, 3),
                        "kernel_ms_avg": round(sum(kernel_ms_color) / len(kernel_ms_color), 3), "pipeline": pipe_color,
                        "note": "same workload, aov_color only (lean kernel instantiation; Default mode writes only this AOV to the PNG)"},
+        "fast_math": fast_block,
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
@@ -354,7 +394,7 @@ def main():
                     "sq_active_inst_any_frac": c["SQ_ACTIVE_INST_ANY"] / max(c["SQ_WAVE_CYCLES"], 1.0),
                     "sq_wait_inst_any_frac": c["SQ_WAIT_INST_ANY"] / max(c["SQ_WAVE_CYCLES"], 1.0)}
 
-        roof = {"kernel": "hjr render kernels (%s, 3 AOVs)" % args.integrator, "kernel_ms_avg": round(avg_ms, 3),
+        roof = {"kernel": "hjr_render_kernel / hjr_wavefront_kernel + hjr_finalize_kernel + tile pre-pass (%s, 3 AOVs); rocprof names in profiles/r03_kernel_stats.csv" % args.integrator, "kernel_ms_avg": round(avg_ms, 3),
                 "kernel_Msamples_per_s": round(samples_per_launch / (avg_ms * 1e-3) / 1e6, 3),
                 "pipeline": pipe_full,
                 "algorithmic": {"bytes_per_sample": round(bps, 1), "GBps": round(algorithmic_gbs, 2),
@@ -368,10 +408,21 @@ def main():
             if v["valu_tflops"] / VALU_PEAK_TFLOPS >= hbm_frac:  # the roof the launch is closer to: vector ALUs (scene served by LDS / L2) ...
                 roof.update({"bound": "valu", "achieved": round(v["valu_tflops"], 3), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                              "frac": round(v["valu_tflops"] / VALU_PEAK_TFLOPS, 5),
-                             "definition": "SQ_INSTS_VALU x (SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU) active lanes x 2 FLOP per launch / live kernel time, vs the fp32 vector peak"})
+                             "definition": "VALU lane-slot utilisation in the peak's units: SQ_INSTS_VALU x (SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU) active lanes, every "
+                                           "instruction counted as one 2-FLOP op, per launch / live kernel time, vs the fp32 vector peak (an upper bound on the useful-FLOP "
+                                           "fraction; `flops` counts the fp32 arithmetic instructions only)"})
             else:  # ... or the memory side (scenes beyond the caches; the wavefront kernels' context traffic)
                 roof.update({"bound": "hbm", "achieved": round(v["hbm_GBps"], 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_frac, 5),
                              "definition": "(FETCH_SIZE x 2 + WRITE_SIZE) counter bytes per launch / live kernel time, vs 8 TB/s (Infinity-Cache hits are counted by FETCH_SIZE)"})
+            if "SQ_INSTS_VALU_FMA_F32" in pmc_full:  # fp32 arithmetic only: fma = 2 FLOP, add / mul / transcendental = 1, x active lanes
+                lanes = v["active_lane_frac"] * 64.0
+                fl = (2.0 * pmc_full["SQ_INSTS_VALU_FMA_F32"] + pmc_full["SQ_INSTS_VALU_ADD_F32"] + pmc_full["SQ_INSTS_VALU_MUL_F32"] + pmc_full["SQ_INSTS_VALU_TRANS_F32"]) * lanes
+                roof["flops"] = {"achieved": round(fl / (avg_ms * 1e-3) / 1e12, 3), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(fl / (avg_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 5),
+                                 "wave_insts": {k[14:].lower(): pmc_full[k] for k in PMC_FLOP_PASS if k.startswith("SQ_INSTS_VALU_")},
+                                 "salu_wave_insts": pmc_full.get("SQ_INSTS_SALU"), "lds_wave_insts": pmc_full.get("SQ_INSTS_LDS"),
+                                 "definition": "(2 x FMA_F32 + ADD_F32 + MUL_F32 + TRANS_F32 wave instructions) x average active lanes / live kernel time"}
+            elif "flop_pass_error" in pmc_full:
+                roof["flops"] = {"error": pmc_full["flop_pass_error"]}
             roof["traffic"] = int(v["hbm_bytes"])
             roof["counters"] = {"source": "rocprofv3 --pmc passes of tools/kbench inside this run (same library, workload, GPU)",
                                 "active_lane_frac": round(v["active_lane_frac"], 4), "valu_wave_insts_per_launch": v["valu_wave_insts"],

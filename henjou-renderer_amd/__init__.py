@@ -19,7 +19,7 @@ ASSETS = os.path.join(PKG_DIR, "assets")
 
 INTEGRATOR_NEE, INTEGRATOR_PT, INTEGRATOR_MIS = 0, 1, 2
 MODE_DEFAULT, MODE_DENOISE, MODE_DENOISE_UPSCALE2X, MODE_DEBUG = 0, 1, 2, 3  # render_option.h:38-43
-FLAG_STATS, FLAG_ZERO_UNOWNED, FLAG_PACKED = 1, 2, 4
+FLAG_STATS, FLAG_ZERO_UNOWNED, FLAG_PACKED, FLAG_FAST_MATH = 1, 2, 4, 8
 
 
 class HjrError(RuntimeError):
@@ -102,11 +102,11 @@ class Stats(_Sized):
                [("last_kernel_ms", C.c_float), ("bvh_nodes", C.c_uint32), ("bvh_depth", C.c_uint32),
                 ("n_triangles", C.c_uint32), ("lds_mode", C.c_uint32), ("stack_need", C.c_uint32),
                 ("stack_lds_entries", C.c_uint32), ("pipeline", C.c_uint32), ("stack_overflow_pushes", C.c_uint64),
-                ("nan_located", C.c_uint32), ("_pad1", C.c_uint32), ("nan_where", (C.c_uint32 * 3) * 8)]
+                ("nan_located", C.c_uint32), ("fast_math", C.c_uint32), ("nan_where", (C.c_uint32 * 3) * 8)]
 
     def as_dict(self):
         d = {n: (float(getattr(self, n)) if n == "last_kernel_ms" else int(getattr(self, n)))
-             for n, _ in self._fields_ if n not in ("struct_size", "_pad0", "_pad1", "nan_where")}
+             for n, _ in self._fields_ if n not in ("struct_size", "_pad0", "nan_where")}
         d["nan_where"] = [tuple(int(v) for v in self.nan_where[i]) for i in range(int(self.nan_located))]  # (x, y, sample)
         return d
 

@@ -106,7 +106,7 @@ static int run_rank(const char* json, int rank, int world, int id_fd)
         HJRX(hjr_scene_eval_camera(scene, &opt, time, &p.camera));
         for (int k = 0; k < 3; k++) p.sky[k] = opt.scene_sky_default[k];
         p.ibl_intensity = opt.IBL_intensity;
-        p.rank = (uint32_t)rank; p.world_size = (uint32_t)world; p.flags = HJR_FLAG_PACKED;
+        p.rank = (uint32_t)rank; p.world_size = (uint32_t)world; p.flags = HJR_FLAG_PACKED | (opt.fast_math ? HJR_FLAG_FAST_MATH : 0u);
         const auto t0 = std::chrono::steady_clock::now();
         HJRX(hjr_render_device(ctx, &p, d_packed, nullptr, nullptr, st));
         NCCLX(ncclGather(d_packed, d_all, block * 4, ncclFloat, 0, comm, st)); // the one data-path collective of a frame

@@ -246,6 +246,13 @@ extern template int hjr_launch<HJR_INTEGRATOR_PT, true>(hjr_ctx*, const KParams&
 extern template int hjr_launch<HJR_INTEGRATOR_MIS, false>(hjr_ctx*, const KParams&, uint64_t, int, hipStream_t);
 extern template int hjr_launch<HJR_INTEGRATOR_MIS, true>(hjr_ctx*, const KParams&, uint64_t, int, hipStream_t);
 #endif
+#if !defined(HJR_LEAN_VARIANT) && !defined(HJR_UNITY)
+template <int I> int hjr_launch_fast(hjr_ctx*, const KParams&, uint64_t, int, hipStream_t); // hjr_launch_fast_*.hip (HJR_FLAG_FAST_MATH)
+extern template int hjr_launch_fast<HJR_INTEGRATOR_NEE>(hjr_ctx*, const KParams&, uint64_t, int, hipStream_t);
+extern template int hjr_launch_fast<HJR_INTEGRATOR_PT>(hjr_ctx*, const KParams&, uint64_t, int, hipStream_t);
+extern template int hjr_launch_fast<HJR_INTEGRATOR_MIS>(hjr_ctx*, const KParams&, uint64_t, int, hipStream_t);
+#define HJR_HAVE_FAST 1
+#endif
 #ifdef HJR_UNITY /* diagnostic variants (make variant): one translation unit, so that the __device__ diagnostic counters are one symbol */
 #ifdef HJR_LEAN_VARIANT /* NEE without the statistics counters only; every other launch runs that kernel too (timing experiments, not pictures) */
 #include "hjr_launch.hip.h"
@@ -406,9 +413,17 @@ static int render_impl(hjr_ctx* c, const hjr_params* p, void* d_color, void* d_a
         kp.tile_order = (const uint32_t*)c->d_tiles.p;
     }
     int lrc = 0;
+    c->stats.fast_math = 0u;
 #ifdef HJR_LEAN_VARIANT
     lrc = hjr_launch<HJR_INTEGRATOR_NEE, false>(c, kp, n_items, lds_mode, st);
 #else
+#ifdef HJR_HAVE_FAST
+    if ((p->flags & HJR_FLAG_FAST_MATH) && !stats) { // approximate-arithmetic kernels (megakernel family); a counting launch stays exact
+        c->stats.fast_math = 1u;
+        lrc = p->integrator == HJR_INTEGRATOR_NEE ? hjr_launch_fast<HJR_INTEGRATOR_NEE>(c, kp, n_items, lds_mode, st)
+            : (p->integrator == HJR_INTEGRATOR_PT ? hjr_launch_fast<HJR_INTEGRATOR_PT>(c, kp, n_items, lds_mode, st) : hjr_launch_fast<HJR_INTEGRATOR_MIS>(c, kp, n_items, lds_mode, st));
+    } else
+#endif
     switch (p->integrator * 2 + (stats ? 1 : 0)) {
     case 0: lrc = hjr_launch<HJR_INTEGRATOR_NEE, false>(c, kp, n_items, lds_mode, st); break;
     case 1: lrc = hjr_launch<HJR_INTEGRATOR_NEE, true>(c, kp, n_items, lds_mode, st); break;

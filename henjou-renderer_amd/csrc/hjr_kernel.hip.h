@@ -247,11 +247,14 @@ struct WaveRange { uint32_t next, end; bool exhausted; SharedRange* shared; };
 #define HJR_WF_ITEM_FETCH 256u /* items per refill of a workgroup's shared range */
 #endif
 // Claims up to n items of the workgroup's shared range for the calling wave (ONE lane calls this): at most two runs of
-// consecutive items, [a0, a0 + n0) and [a1, a1 + n1).  n0 + n1 < n only when the frame has no more items for this workgroup.
-HD void shared_claim(const KParams& P, SharedRange* S, uint32_t n, uint32_t& a0, uint32_t& n0, uint32_t& a1, uint32_t& n1)
+// consecutive items, [a0, a0 + n0) and [a1, a1 + n1).  Returns true ("dry") when it stopped because the frame has no more items for
+// this workgroup; n0 + n1 < n with false means that other waves drained the refilled range first — under contention two runs can both
+// be short — and the lanes left without an item must ask again (they are NOT finished: the wavefront kernel re-queues them).
+HD bool shared_claim(const KParams& P, SharedRange* S, uint32_t n, uint32_t& a0, uint32_t& n0, uint32_t& a1, uint32_t& n1)
 {
     a0 = a1 = n0 = n1 = 0u;
     uint32_t left = n;
+    bool dry = false;
     while (left) {
         const unsigned long long old = __hip_atomic_load(&S->range, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         const uint32_t nx = (uint32_t)old, en = (uint32_t)(old >> 32);
@@ -260,10 +263,10 @@ HD void shared_claim(const KParams& P, SharedRange* S, uint32_t n, uint32_t& a0,
             if (atomicCAS(&S->range, old, (unsigned long long)(nx + take) | ((unsigned long long)en << 32)) != old) continue;
             if (n0 == 0u) { a0 = nx; n0 = take; } else { a1 = nx; n1 = take; }
             left -= take;
-            if (n1) break; // two runs are all a caller can take (ranges are HJR_WF_ITEM_FETCH >= 64 items unless the frame ends)
+            if (n1) break; // two runs are all a caller can take; whoever is still without an item asks again
             continue;
         }
-        if (__hip_atomic_load(&S->exhausted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+        if (__hip_atomic_load(&S->exhausted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) { dry = true; break; }
         if (atomicCAS(&S->lock, 0u, 1u) == 0u) { // this wave refills (unless another one just did)
             const unsigned long long now = __hip_atomic_load(&S->range, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if ((uint32_t)now == (uint32_t)(now >> 32)) {
@@ -274,6 +277,7 @@ HD void shared_claim(const KParams& P, SharedRange* S, uint32_t n, uint32_t& a0,
             __hip_atomic_store(&S->lock, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         } else __builtin_amdgcn_s_sleep(2);
     }
+    return dry;
 }
 
 // NaN/Inf guard + ordered accumulation of one finished sample
@@ -366,9 +370,11 @@ HD void bounce_pre_trace(const KParams& P, LaneCtx& c, WaveRange& wr, const bool
             const uint32_t n = (uint32_t)__popcll(m);
             const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
             uint32_t q;
+            bool again = false; // shared range only: unserved lanes ask again in their next pass instead of retiring
             if (wr.shared) { // wavefront kernel: the workgroup's shared range
-                uint32_t a0 = 0, n0 = 0, a1 = 0, n1 = 0;
-                if (lane == 0) shared_claim(P, wr.shared, n, a0, n0, a1, n1);
+                uint32_t a0 = 0, n0 = 0, a1 = 0, n1 = 0, dry = 1u;
+                if (lane == 0) dry = shared_claim(P, wr.shared, n, a0, n0, a1, n1) ? 1u : 0u;
+                again = __builtin_amdgcn_readfirstlane((int)dry) == 0;
                 a0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)a0); n0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)n0);
                 a1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)a1); n1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)n1);
                 q = prefix < n0 ? a0 + prefix : (prefix - n0 < n1 ? a1 + (prefix - n0) : 0xffffffffu);
@@ -429,7 +435,7 @@ HD void bounce_pre_trace(const KParams& P, LaneCtx& c, WaveRange& wr, const bool
                         if (AOVS && c.aov) c.aov[0] = c.aov[1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                         else { c.sumA = V1(0.0f); c.sumN = V1(0.0f); }
                     }
-                } else c.dead = true;
+                } else if (!again) c.dead = true;
             }
         }
     }
@@ -622,7 +628,9 @@ HD void stage_scene_in_lds(const KParams& P, float4* base, const float4*& nodes,
 // VAR: 0 = lean (colour only, untextured scene, constant sky), 1 = + albedo / normal AOV sums, 2 = + material textures, normal maps
 // and the equirect sky texture.  Each step costs registers (NEE, LDS layout: 20 / 25 / 48 VGPR spills), so a launch gets the
 // smallest variant that does what it needs.
-template <int INTEGRATOR, bool STATS, int BLOCK, bool LDSBVH, bool STACK16, int WIDTH, int VAR>
+// FAST only tags the symbol: the HJR_FAST_MATH translation units (hjr_launch_fast_*.hip; approximate division / square root / sine / cosine /
+// power in the SHADING code, traversal and triangle test unchanged) instantiate FAST = true, the exact ones FAST = false.
+template <int INTEGRATOR, bool STATS, int BLOCK, bool LDSBVH, bool STACK16, int WIDTH, int VAR, bool FAST = false>
 __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_render_kernel(const KParams P)
 {
     constexpr bool AOVS = VAR >= 1, TEX = VAR == 2;

@@ -71,6 +71,11 @@ struct hjr_ctx {
 };
 
 
+#ifdef HJR_FAST_MATH
+#define HJR_FAST_TAG true
+#else
+#define HJR_FAST_TAG false
+#endif
 template <int I, bool S, int W> static int launch_mem(hjr_ctx* c, const KParams& kp, uint64_t n_items, hipStream_t st);
 template <int I, bool S, int W, int A> static int launch_mem2(hjr_ctx* c, const KParams& kp, uint64_t n_items, hipStream_t st);
 // kernel variant of a launch (VAR of hjr_render_kernel / hjr_wavefront_kernel): 2 textures / sky texture, 1 albedo / normal AOVs, 0 colour only
@@ -79,7 +84,7 @@ static int kernel_variant(const KParams& kp) { return (kp.tex_desc || kp.sky_tex
 template <int I, bool S, bool S16, int A> static int launch_lds2(hjr_ctx* c, const KParams& kp, uint64_t n_items, hipStream_t st)
 {
     const size_t smem = (((size_t)HJR_BLOCK_LDS * kp.stack_depth * (S16 ? 2 : 4) + 15) / 16) * 16 + ((size_t)kp.n_node_f4 + kp.n_tri_f4 + kp.n_mat_f4 + kp.n_light_f4) * 16;
-    auto kern = hjr_render_kernel<I, S, HJR_BLOCK_LDS, true, S16, 2, A>;
+    auto kern = hjr_render_kernel<I, S, HJR_BLOCK_LDS, true, S16, 2, A, HJR_FAST_TAG>;
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return -1;
     uint64_t blocks = (uint64_t)c->n_cus;
     uint64_t max_useful = (n_items + HJR_BLOCK_LDS - 1) / HJR_BLOCK_LDS;
@@ -223,7 +228,7 @@ template <int I, bool S, int W, int A> static int launch_mem2(hjr_ctx* c, const 
     const uint32_t short_stack = (uint32_t)c->opt.get(hjr::OPT_SHORT_STACK, HJR_SHORT_STACK); // tests force the overflow path with 2
     const uint32_t lds_entries = kp.stack_depth < short_stack ? kp.stack_depth : short_stack;
     const size_t smem = (size_t)HJR_BLOCK * lds_entries * 4;
-    auto kern = hjr_render_kernel<I, S, HJR_BLOCK, false, false, W, A>;
+    auto kern = hjr_render_kernel<I, S, HJR_BLOCK, false, false, W, A, HJR_FAST_TAG>;
     int per_cu = 0;
     if (c->opt.is_set(hjr::OPT_BLOCKS_PER_CU)) per_cu = c->opt.get(hjr::OPT_BLOCKS_PER_CU, 0);
     else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, HJR_BLOCK, smem) != hipSuccess || per_cu < 1)
@@ -246,3 +251,19 @@ template <int I, bool S, int W, int A> static int launch_mem2(hjr_ctx* c, const 
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(HJR_BLOCK), smem, st, k2);
     return 0;
 }
+
+#ifdef HJR_FAST_MATH
+// HJR_FLAG_FAST_MATH launches: the megakernel family of this (approximate-arithmetic) translation unit, every layout; no counting variant
+template <int I> int hjr_launch_fast(hjr_ctx* c, const KParams& kp_in, uint64_t n_items, int lds_mode, hipStream_t st)
+{
+    KParams kp = kp_in;
+    const bool lds_layout = lds_mode == 1 || lds_mode == 2;
+    c->stats.pipeline = 0u;
+    kp.hold_min = (uint32_t)c->opt.get(hjr::OPT_HOLD_MIN, HJR_HOLD_MIN); kp.hold_age = (uint32_t)c->opt.get(hjr::OPT_HOLD_AGE, HJR_HOLD_AGE);
+    kp.node_min = (uint32_t)c->opt.get(hjr::OPT_NODE_MIN, lds_layout ? HJR_NODE_MIN_LDS : HJR_NODE_MIN_MEM);
+    if (lds_mode == 1) return launch_lds<I, false, false>(c, kp, n_items, st);
+    if (lds_mode == 2) return launch_lds<I, false, true>(c, kp, n_items, st);
+    if (lds_mode == 3) return launch_mem<I, false, 2>(c, kp, n_items, st);
+    return launch_mem<I, false, 4>(c, kp, n_items, st);
+}
+#endif

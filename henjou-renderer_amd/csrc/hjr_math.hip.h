@@ -44,9 +44,38 @@ HD float absdot(f3 a, f3 b) { return fabsf(dot(a, b)); }
 HD float bits2f(uint32_t u) { return __uint_as_float(u); }
 HD uint32_t f2bits(float f) { return __float_as_uint(f); }
 
-// ---- portable transcendental set
+// Correctly rounded fp32 division spelled out with the hardware's division helpers (scale, reciprocal, Newton steps with fma, fixup): the
+// sequence a compiler emits for `a / b` under -fhip-fp32-correctly-rounded-divide-sqrt.  The ray / triangle test uses it, so that its bits
+// do not depend on the flags of the translation unit (the HJR_FAST_MATH units compile `/` as a multiplication by v_rcp_f32).
+HD float exact_div(float a, float b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    bool vcc;
+    const float ds = __builtin_amdgcn_div_scalef(a, b, false, &vcc); // the denominator, scaled
+    const float ns = __builtin_amdgcn_div_scalef(a, b, true, &vcc);  // the numerator, scaled; vcc: the quotient needs the final scaling
+    float r = __builtin_amdgcn_rcpf(ds);
+    const float e = __builtin_fmaf(-ds, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);
+    float q = ns * r;
+    float t = __builtin_fmaf(-ds, q, ns);
+    q = __builtin_fmaf(t, r, q);
+    t = __builtin_fmaf(-ds, q, ns);
+    return __builtin_amdgcn_div_fixupf(__builtin_amdgcn_div_fmasf(t, r, q, vcc), b, a);
+#else
+    return a / b;
+#endif
+}
+
+// ---- portable transcendental set (exact kernels); HJR_FAST_MATH translation units take the hardware's approximations instead
+#ifdef HJR_FAST_MATH
+#define HJR_FAST_SINCOS(x, s, c) { s = __sinf(x); c = __cosf(x); }
+#endif
 HD void p_sincos(float x, float& s, float& c)
 {
+#ifdef HJR_FAST_MATH
+    HJR_FAST_SINCOS(x, s, c)
+    return;
+#endif
     float fj = floorf(x * 0.636619772367581343f + 0.5f);
     int j = (int)fj;
     float r = fmaf(fj, -1.5703125f, x);
@@ -123,6 +152,9 @@ HD float p_exp(float x)
 }
 HD float p_pow(float x, float y)
 {
+#ifdef HJR_FAST_MATH
+    return __powf(x, y); // v_log_f32, multiply, v_exp_f32
+#endif
     if (y == 0.0f) return 1.0f;
     if (x == 1.0f) return 1.0f;
     if (x != x || y != y) return x + y;

@@ -3,6 +3,10 @@
 #pragma once
 #include "hjr_params.hip.h"
 
+#ifdef HJR_FAST_MATH /* the traversal and the triangle test are the same operations in every build: no mul + add fusion here */
+#pragma clang fp contract(off)
+#endif
+
 // ------------------------------------------------------------------ traversal: replaces optixTrace (kernel/rt.h:15-69) + RT cores
 struct Counters {
     uint32_t box, tri;
@@ -21,7 +25,7 @@ HD bool ray_tri(f3 v0, f3 v1, f3 v2, f3 o, f3 d, float tmin, float tmax, float& 
     f3 p = crossf(d, e2);
     float det = dotf(e1, p);
     if (det == 0.0f) return false;
-    float inv = 1.0f / det;
+    float inv = exact_div(1.0f, det); // == 1.0f / det, whatever the division flags of the translation unit
     f3 tv = o - v0;
     float u = dotf(tv, p) * inv;
     if (!(u >= 0.0f && u <= 1.0f)) return false;
@@ -366,3 +370,7 @@ HD bool traverse_fused(const float4* nodes, const float4* tris, const bool a_val
     if (CARRY > 0) { tc.phase = phase; tc.sp = sp; tc.cur = cur; return phase < 2; }
     return false;
 }
+
+#ifdef HJR_FAST_MATH
+#pragma clang fp contract(fast)
+#endif

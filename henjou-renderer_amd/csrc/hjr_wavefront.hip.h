@@ -212,6 +212,7 @@ HD void wf_push_shade(WfShared* Q, wf_ring_ptr rings, uint32_t e0, uint32_t e1, 
 // The albedo / normal sums of a launch with those AOVs live in a second array (HJR_WF_AOV_F4 float4 per context: sumA, sumN): they
 // change once per SAMPLE (first hit: a read-modify-write there, LaneCtx::aov), the record is read and written once per BOUNCE by two
 // stages — carrying them in the record (192 bytes, records straddling cache lines) cost 16 ms of 131 on the bundled scene.
+#define HJR_MAX_DRAWS_PER_BOUNCE 26 /* 1 + 2 + 1 + 2 x 11, see wf_store_ctx */
 #define HJR_WF_CTX_F4 8
 #define HJR_WF_AOV_F4 2
 HD void wf_store_ctx(float4* ctx, uint32_t id, const LaneCtx& c, bool tracing)
@@ -224,8 +225,12 @@ HD void wf_store_ctx(float4* ctx, uint32_t id, const LaneCtx& c, bool tracing)
     p[2] = make_float4(c.sh_d.x, c.sh_d.y, c.sh_d.z, bits2f(c.item));
     p[3] = make_float4(c.ps.thr.x, c.ps.thr.y, c.ps.thr.z, bits2f(c.s));
     p[4] = make_float4(c.ps.L.x, c.ps.L.y, c.ps.L.z, c.mis_contrib.x);
-    // depth <= 10, rng_depth <= ~300 draws per path, it_cost <= 64 samples x 10 rays per item
-    p[5] = make_float4(c.sumL.x, c.sumL.y, c.sumL.z, bits2f(((uint32_t)c.ps.depth & 0xffu) | ((c.ps.rng_depth & 0xfffu) << 8) | ((c.it_cost & 0xfffu) << 20)));
+    // depth <= 10 (8 bits).  rng_depth (12 bits): CMJ draws of the path so far; a bounce draws at most HJR_MAX_DRAWS_PER_BOUNCE numbers (roulette 1,
+    // light sample 2, the reference's discarded 2-D draw 1, a BSDF sample at most 11 — the multiple-scattering GGX walk: 6 heights + 5 normals —, twice
+    // for MIS), a path at most 1 + 10 of those: checked below.  it_cost (12 bits) is a scheduling hint (closest-hit rays of the item so far,
+    // hjr_cost_hist_kernel): it SATURATES instead of wrapping, so a long item can never look cheap.
+    static_assert(1 + 10 * HJR_MAX_DRAWS_PER_BOUNCE < 4096, "rng_depth no longer fits its 12 bits of the context record");
+    p[5] = make_float4(c.sumL.x, c.sumL.y, c.sumL.z, bits2f(((uint32_t)c.ps.depth & 0xffu) | ((c.ps.rng_depth & 0xfffu) << 8) | (min(c.it_cost, 0xfffu) << 20)));
     p[6] = make_float4(c.sh_contrib.x, c.sh_contrib.y, c.sh_contrib.z, c.mis_contrib.y);
     reinterpret_cast<float*>(p + 7)[0] = c.mis_contrib.z;
 }

@@ -349,6 +349,7 @@ extern "C" int hjr_render_file(const char* render_option_json, int device)
         for (int k = 0; k < 3; k++) p.sky[k] = opt.scene_sky_default[k];
         p.ibl_intensity = opt.IBL_intensity;
         p.rank = 0; p.world_size = 1;
+        if (opt.fast_math) p.flags |= HJR_FLAG_FAST_MATH; // "Henjou_HIP": {"fast_math": true}
         Slot& sl = slots[cur];
         if (!serial_io) { // the slot may still be with the writer (two frames behind)
             std::unique_lock<std::mutex> lk(mu);

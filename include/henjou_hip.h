@@ -162,6 +162,12 @@ typedef struct hjr_params {
                                   * tile 64 float4 in row-major 8x8 order (hjr_owned_tiles(..) x 64 float4 per AOV).  What a
                                   * multi-GPU frame exchanges: 1 / world_size of the frame per rank, no zero fill */
 
+#define HJR_FLAG_FAST_MATH 8u    /* opt-in: the approximate-arithmetic kernels — hardware reciprocal / square root / sine / cosine / power and fused
+                                  * multiply-adds in the SHADING code, as the reference's own build does (nvcc --use_fast_math: div.approx, sqrt.approx,
+                                  * sin.approx in lib/ptx); traversal and ray / triangle test unchanged.  Frames are NOT bit-identical to the default
+                                  * (exact) kernels: they agree within the metric's tolerance (per-pixel RMSE < 1e-3 at 1024 spp; tests/test_gpu_fast_math.py).
+                                  * Megakernel family only; ignored by HJR_FLAG_STATS launches. */
+
 typedef struct hjr_stats {
     uint32_t struct_size;        /* sizeof(hjr_stats) of the caller (HJR_INIT) */
     uint32_t _pad0;
@@ -178,7 +184,8 @@ typedef struct hjr_stats {
     uint64_t stack_overflow_pushes; /* HJR_FLAG_STATS launches: stack pushes that went to the HBM overflow (memory-path layouts) */
     /* HJR_FLAG_STATS launches: where NaN / Inf samples came from (they are zeroed and counted in nan_samples; the reference has no
      * guard and would emit a NaN pixel): the first nan_located <= 8 of them in no particular order, as (pixel x, pixel y, sample) */
-    uint32_t nan_located, _pad1;
+    uint32_t nan_located;
+    uint32_t fast_math;          /* 1: the last launch ran the HJR_FLAG_FAST_MATH kernels */
     uint32_t nan_where[8][3];
 } hjr_stats;
 

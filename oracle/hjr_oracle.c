@@ -14,6 +14,7 @@
 #include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
+#include <stdio.h>
 
 typedef struct { float x, y, z; } f3;
 typedef struct { float x, y; } f2;
@@ -1175,6 +1176,11 @@ static float getLightPDF(tctx* T, uint32_t primID, uint32_t instID)
 }
 
 /* NEE (rt.h:162-281) */
+/* Test-infrastructure aid: with hjo_set_trace(1) the NEE integrator narrates a sample on stderr (used once to find the expression behind
+ * the NaN samples of the C2 frame). */
+static int hjo_trace = 0;
+void hjo_set_trace(int on) { hjo_trace = on; }
+#define TR(...) do { if (hjo_trace) fprintf(stderr, __VA_ARGS__); } while (0)
 static f3 NEE(tctx* T, f3 o, f3 d, cmj_state state, f3* aov_albedo, f3* aov_normal)
 {
     const hjo_scene* s = &T->c->sc; int mm = T->c->mm;
@@ -1193,6 +1199,9 @@ static f3 NEE(tctx* T, f3 o, f3 d, cmj_state state, f3* aov_albedo, f3* aov_norm
         f3 t, b, n = prd.normal;
         orthonormal_basis(n, &t, &b);
         f3 local_wo = world_to_local(neg(rd), t, n, b);
+        TR("depth %d: prim %d basecolor %g %g %g metallic %g roughness %g sheen %g clearcoat %g ior %g specular %d thinfilm %d | n %g %g %g (|n|^2 %.9g) wo_local %g %g %g thr %g %g %g\n", depth, (int)prd.primitive_id,
+           prd.basecolor.x, prd.basecolor.y, prd.basecolor.z, prd.metallic, prd.roughness, prd.sheen, prd.clearcoat, prd.ior, (int)prd.is_specular, (int)prd.is_thinfilm,
+           n.x, n.y, n.z, dot(n, n), local_wo.x, local_wo.y, local_wo.z, throughput.x, throughput.y, throughput.z);
         { /* NEE */
             float light_pdf; f3 light_color, light_normal; int valid;
             f3 light_position = light_sample(T, &state, &light_pdf, &light_normal, &light_color, &valid);
@@ -1210,6 +1219,7 @@ static f3 NEE(tctx* T, f3 o, f3 d, cmj_state state, f3* aov_albedo, f3* aov_norm
                 f3 bsdf = bsdf_eval(&bs, local_wo, local_wi);
                 float G = cosine2 / (light_distance * light_distance);
                 f3 contrib = mul(mul(throughput, divs(muls(muls(bsdf, G), cosine1), light_pdf)), light_color);
+                TR("   nee: wi_local %g %g %g bsdf_eval %g %g %g G %g cos1 %g light_pdf %g contrib %g %g %g\n", local_wi.x, local_wi.y, local_wi.z, bsdf.x, bsdf.y, bsdf.z, G, cosine1, light_pdf, contrib.x, contrib.y, contrib.z);
                 if (!(contrib.x == 0.0f && contrib.y == 0.0f && contrib.z == 0.0f) &&
                     !TraceOcclusion(T, so, sd, 0.001f, light_distance - ipsiron_distance))
                     LTE = add(LTE, contrib);
@@ -1221,6 +1231,7 @@ static f3 NEE(tctx* T, f3 o, f3 d, cmj_state state, f3* aov_albedo, f3* aov_norm
         f3 bsdf = bsdf_sample(&bs, local_wo, &local_wi, &pdf, &state);
         f3 wi = local_to_world(local_wi, t, n, b);
         throughput = mul(throughput, divs(muls(bsdf, fabsf(dot(wi, n))), pdf));
+        TR("   sample: wi_local %g %g %g bsdf %g %g %g pdf %g -> thr %g %g %g  LTE %g %g %g\n", local_wi.x, local_wi.y, local_wi.z, bsdf.x, bsdf.y, bsdf.z, pdf, throughput.x, throughput.y, throughput.z, LTE.x, LTE.y, LTE.z);
         ro = prd.position; rd = wi;
     }
     return LTE;

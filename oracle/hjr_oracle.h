@@ -100,6 +100,8 @@ void     hjo_destroy(hjo_ctx*);
 int hjo_render(hjo_ctx*, const hjo_params*, float* color, float* albedo, float* normal,
                int nthreads, hjo_stats* stats);
 /* One (pixel, sample): radiance[3], albedo[3], normal[3]. */
+/* narrate NEE samples on stderr (test aid) */
+void hjo_set_trace(int on);
 int hjo_sample(hjo_ctx*, const hjo_params*, uint32_t x, uint32_t y, uint32_t s,
                 float* radiance, float* albedo, float* normal);
 

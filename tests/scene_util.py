@@ -36,6 +36,14 @@ class device_options:
         return False
 
 
+def new_device(options=None):
+    """hjr.Device(0) with the DEVICE_OPTIONS of the enclosing `device_options` blocks (and `options`) applied."""
+    d = hjr.Device(0)
+    for k, v in dict(DEVICE_OPTIONS, **(options or {})).items():
+        d.set_option(k, v)
+    return d
+
+
 class Cornell:
     """cornelbox.gltf loaded via libhenjou_hip.so's scene surface, at frame 1 (t = 1/24 s)."""
 
@@ -67,9 +75,7 @@ class Cornell:
     def device(self, options=None):
         """A device context with this scene resident.  `options` (and the module-wide DEVICE_OPTIONS the `device_options` context manager
         sets) go through hjr_set_option BEFORE the frame data is built, so that layout options act on it."""
-        d = hjr.Device(0)
-        for k, v in dict(DEVICE_OPTIONS, **(options or {})).items():
-            d.set_option(k, v)
+        d = new_device(options)
         d.upload_scene(self.scene.view)
         d.set_transforms(self.arrays["transforms"], self.arrays["inv_transforms"])
         return d

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import oracle_binding as ob
-from scene_util import Cornell, StressScene, hjr, load_lut
+from scene_util import new_device, Cornell, StressScene, hjr, load_lut
 from test_gpu_parity import assert_bitexact
 
 pytestmark = pytest.mark.gpu
@@ -132,7 +132,7 @@ def test_random_materials_and_cameras():
         a["lut_rgba"] = lut
         cam = dict(base.camera.as_dict())
         cam["pos"] = [float(cam["pos"][0] - rng.uniform(0, 2.5)), float(rng.uniform(-0.5, 0.5)), float(rng.uniform(-0.5, 0.5))]
-        d = hjr.Device(0)
+        d = new_device()
         try:
             d.upload_arrays(a)
             d.set_transforms(a["transforms"], a["inv_transforms"])
@@ -160,7 +160,7 @@ def test_no_lights_and_black_sky():
     a["materials"] = mats
     a["light_prim_ids"] = np.zeros(0, np.uint32)
     a["light_prim_emission"] = np.zeros(0, np.float32)
-    d = hjr.Device(0)
+    d = new_device()
     try:
         d.upload_arrays(a)
         d.set_transforms(a["transforms"], a["inv_transforms"])
@@ -201,7 +201,7 @@ def test_empty_scene_is_all_sky(pipe):
     a.update(vertices=z, normals=z, texcoords=z, indices=np.zeros(0, np.uint32), material_ids=np.zeros(0, np.uint32),
              prim_offsets=np.zeros(0, np.uint32), light_prim_ids=np.zeros(0, np.uint32), light_prim_emission=z)
     with knobs(HJR_PIPELINE=pipe):
-        d = hjr.Device(0)
+        d = new_device()
         try:
             d.upload_arrays(a)
             d.set_transforms(np.zeros((0, 12), np.float32), np.zeros((0, 12), np.float32))

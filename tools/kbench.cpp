@@ -1,6 +1,6 @@
 // tools/kbench — kernel-variant bench over the C-ABI, no Python / torch start-up cost.
 //   kbench <libhenjou_hip.so> <render_option.json> [--width W] [--height H] [--spp S] [--integrator 0|1|2] [--reps N]
-//          [--aovs] [--rank r --world n] [--stats]
+//          [--aovs] [--rank r --world n] [--stats] [--fast]
 // dlopens the given build of the library (so several builds can be compared inside one gpurun call), renders the start frame of
 // the config `reps` times through hjr_render (host buffers; the kernel time is the library's own HIP-event time around the
 // kernels) and prints kernel ms (min / mean), Msamples/s and an FNV-1a hash of the colour AOV (equal hashes = bit-identical
@@ -31,7 +31,7 @@ int main(int argc, char** argv)
 #define CHK(call) do { int rc_ = (call); if (rc_ != HJR_OK) { fprintf(stderr, "kbench: %s -> %d: %s\n", #call, rc_, p_hjr_last_error()); return 1; } } while (0)
     CHK(p_hjr_load_render_option(argv[2], &opt));
     int reps = 3, rank = 0, world = 1;
-    bool aovs = false, stats = false;
+    bool aovs = false, stats = false, fast = false;
     for (int i = 3; i < argc; i++) {
         std::string a = argv[i];
         auto val = [&]() { return (i + 1 < argc) ? atoi(argv[++i]) : 0; };
@@ -44,6 +44,7 @@ int main(int argc, char** argv)
         else if (a == "--world") world = val();
         else if (a == "--aovs") aovs = true;
         else if (a == "--stats") stats = true;
+        else if (a == "--fast") fast = true;
         else { fprintf(stderr, "kbench: unknown option %s\n", a.c_str()); return 2; }
     }
     hjr_scene* scene = nullptr;
@@ -70,7 +71,7 @@ int main(int argc, char** argv)
     for (int k = 0; k < 3; k++) p.sky[k] = opt.scene_sky_default[k];
     p.ibl_intensity = opt.IBL_intensity;
     p.rank = (uint32_t)rank; p.world_size = (uint32_t)world;
-    p.flags = (stats ? HJR_FLAG_STATS : 0u) | (world > 1 ? HJR_FLAG_PACKED : 0u); // a rank of a shard renders packed tiles, as bench.py and henjou_cli do
+    p.flags = (stats ? HJR_FLAG_STATS : 0u) | (world > 1 ? HJR_FLAG_PACKED : 0u) | (fast ? HJR_FLAG_FAST_MATH : 0u); // a rank of a shard renders packed tiles, as bench.py and henjou_cli do
     const size_t npx = (size_t)p.width * p.height;
     std::vector<float> color(npx * 4), albedo(aovs ? npx * 4 : 0), normal(aovs ? npx * 4 : 0);
     double sum = 0, best = 1e30;

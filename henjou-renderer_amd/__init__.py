@@ -76,7 +76,7 @@ class RenderOption(_Sized):
                 ("use_IBL", C.c_int32), ("IBL_path", C.c_char * 512), ("IBL_intensity", C.c_float),
                 ("scene_sky_default", C.c_float * 3), ("use_date", C.c_int32), ("save_renderOption", C.c_int32),
                 ("LUT_path", C.c_char * 512), ("seed", C.c_uint32), ("integrator", C.c_int32),
-                ("devices", C.c_uint32), ("tile", C.c_uint32), ("serial_io", C.c_int32), ("fast_math", C.c_int32)]
+                ("devices", C.c_uint32), ("tile", C.c_uint32), ("serial_io", C.c_int32), ("fast_math", C.c_int32), ("force_rebuild", C.c_int32)]
 
 
 class Camera(C.Structure):

@@ -280,6 +280,19 @@ HD bool shared_claim(const KParams& P, SharedRange* S, uint32_t n, uint32_t& a0,
     return dry;
 }
 
+// Launch parameters that only the start and the end of a work item need (tile list, queue head, output and chunk-sum pointers, shard
+// geometry) are read from the kernel-argument segment WHERE they are used instead of living in SGPRs for the whole kernel: the render
+// loop keeps ~100 scalar values alive, and every one of these that stays resident pushes another into a VGPR lane (v_writelane at entry,
+// v_readlane at each use: VALU instructions inside the round loop).  The empty asm makes the base pointer opaque, so the compiler can
+// neither hoist the load out of the loop nor merge it with the by-value copy of P.
+template <typename T> HD T cold_param(size_t offset)
+{
+    const char __attribute__((address_space(4)))* ka = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));
+    return *reinterpret_cast<const T __attribute__((address_space(4)))*>(ka + offset);
+}
+#define HJR_COLD(field) cold_param<decltype(KParams::field)>(offsetof(KParams, field))
+
 // NaN/Inf guard + ordered accumulation of one finished sample
 template <bool STATS> HD void finish_sample(const KParams& P, LaneCtx& c, f3 L, unsigned long long* lc, const uint32_t s_back = 0u) // s_back = 1: the sample before c.s (its bookkeeping was closed while the shadow ray was pending)
 {
@@ -305,22 +318,33 @@ HD void close_sample(const KParams& P, LaneCtx& c)
 template <bool AOVS> HD void write_out(const KParams& P, LaneCtx& c)
 {
     const float inv_spp = 1.0f / (float)P.spp;
+    const uint32_t tiles_x = HJR_COLD(tiles_x), world = HJR_COLD(world), n_chunks = HJR_COLD(n_chunks); // (cold parameters: see cold_param)
     // AOV element of the pixel: row-major frame, or (HJR_FLAG_PACKED) this rank's tiles back to back: (owned tile index) * 64 + pixel in tile
-    const size_t pix = P.packed ? (size_t)(hjr_tile_id(HJR_PX(c) / HJR_TILE, HJR_PY(c) / HJR_TILE, P.tiles_x) / P.world) * 64u + ((HJR_PY(c) & 7u) * 8u + (HJR_PX(c) & 7u))
-                                : (size_t)HJR_PX(c) + (size_t)HJR_PY(c) * P.width;
+    const size_t pix = HJR_COLD(packed) ? (size_t)(hjr_tile_id(HJR_PX(c) / HJR_TILE, HJR_PY(c) / HJR_TILE, tiles_x) / world) * 64u + ((HJR_PY(c) & 7u) * 8u + (HJR_PX(c) & 7u))
+                                        : (size_t)HJR_PX(c) + (size_t)HJR_PY(c) * P.width;
     f3 sumA = c.sumA, sumN = c.sumN;
     if (AOVS && c.aov) { const float4 a = c.aov[0], n = c.aov[1]; sumA = V(a.x, a.y, a.z); sumN = V(n.x, n.y, n.z); }
-    if (P.n_chunks == 1u) { // the item is the whole pixel: mean = chunk sum * (1 / spp)
-        P.aov_color[pix] = make_float4(c.sumL.x * inv_spp, c.sumL.y * inv_spp, c.sumL.z * inv_spp, 1.0f);
-        if (AOVS && P.aov_albedo) P.aov_albedo[pix] = make_float4(sumA.x * inv_spp, sumA.y * inv_spp, sumA.z * inv_spp, 1.0f);
-        if (AOVS && P.aov_normal) P.aov_normal[pix] = make_float4(sumN.x * inv_spp, sumN.y * inv_spp, sumN.z * inv_spp, 1.0f);
+    if (n_chunks == 1u) { // the item is the whole pixel: mean = chunk sum * (1 / spp)
+        float4* const aov_color = HJR_COLD(aov_color);
+        aov_color[pix] = make_float4(c.sumL.x * inv_spp, c.sumL.y * inv_spp, c.sumL.z * inv_spp, 1.0f);
+        if (AOVS) {
+            float4* const aov_albedo = HJR_COLD(aov_albedo);
+            float4* const aov_normal = HJR_COLD(aov_normal);
+            if (aov_albedo) aov_albedo[pix] = make_float4(sumA.x * inv_spp, sumA.y * inv_spp, sumA.z * inv_spp, 1.0f);
+            if (aov_normal) aov_normal[pix] = make_float4(sumN.x * inv_spp, sumN.y * inv_spp, sumN.z * inv_spp, 1.0f);
+        }
     } else { // chunk sum -> HBM; hjr_finalize_kernel adds the chunks of a pixel in chunk order.  The buffers hold this rank's
              // tiles only: slot = ((chunk * owned tiles) + owned tile index) * 64 + pixel in tile
-        const uint32_t otile = hjr_tile_id(HJR_PX(c) / HJR_TILE, HJR_PY(c) / HJR_TILE, P.tiles_x) / P.world;
-        const size_t slot = ((size_t)HJR_CHUNK(c) * P.n_owned_tiles + otile) * 64u + ((HJR_PY(c) & 7u) * 8u + (HJR_PX(c) & 7u));
-        P.part_color[slot] = make_float4(c.sumL.x, c.sumL.y, c.sumL.z, 0.0f);
-        if (AOVS && P.part_albedo) P.part_albedo[slot] = make_float4(sumA.x, sumA.y, sumA.z, 0.0f);
-        if (AOVS && P.part_normal) P.part_normal[slot] = make_float4(sumN.x, sumN.y, sumN.z, 0.0f);
+        const uint32_t otile = hjr_tile_id(HJR_PX(c) / HJR_TILE, HJR_PY(c) / HJR_TILE, tiles_x) / world;
+        const size_t slot = ((size_t)HJR_CHUNK(c) * HJR_COLD(n_owned_tiles) + otile) * 64u + ((HJR_PY(c) & 7u) * 8u + (HJR_PX(c) & 7u));
+        float4* const part_color = HJR_COLD(part_color);
+        part_color[slot] = make_float4(c.sumL.x, c.sumL.y, c.sumL.z, 0.0f);
+        if (AOVS) {
+            float4* const part_albedo = HJR_COLD(part_albedo);
+            float4* const part_normal = HJR_COLD(part_normal);
+            if (part_albedo) part_albedo[slot] = make_float4(sumA.x, sumA.y, sumA.z, 0.0f);
+            if (part_normal) part_normal[slot] = make_float4(sumN.x, sumN.y, sumN.z, 0.0f);
+        }
     }
     c.write_pending = false;
 }
@@ -369,6 +393,10 @@ HD void bounce_pre_trace(const KParams& P, LaneCtx& c, WaveRange& wr, const bool
         if (m) {
             const uint32_t n = (uint32_t)__popcll(m);
             const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            // (cold parameters, read here and not kept in SGPRs across the render loop: see cold_param)
+            const uint32_t n_owned_items = HJR_COLD(n_owned_items), n_chunks = HJR_COLD(n_chunks), tiles_x = HJR_COLD(tiles_x), world = HJR_COLD(world);
+            const uint32_t* const tile_order = HJR_COLD(tile_order);
+            uint32_t* const tile_cost = HJR_COLD(tile_cost);
             uint32_t q;
             bool again = false; // shared range only: unserved lanes ask again in their next pass instead of retiring
             if (wr.shared) { // wavefront kernel: the workgroup's shared range
@@ -386,9 +414,9 @@ HD void bounce_pre_trace(const KParams& P, LaneCtx& c, WaveRange& wr, const bool
                 // overshoots n_owned_items by at most 64 per wave of the grid and cannot wrap (hjr_device.hip keeps that margin)
                 uint32_t base = 0xffffffffu;
                 if (!wr.exhausted) {
-                    if (lane == 0) base = atomicAdd(P.queue_head, 64u);
+                    if (lane == 0) base = atomicAdd(HJR_COLD(queue_head), 64u);
                     base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                    wr.exhausted = base >= P.n_owned_items;
+                    wr.exhausted = base >= n_owned_items;
                 }
                 if (wr.exhausted) {
                     if (prefix >= have) q = 0xffffffffu;
@@ -403,28 +431,28 @@ HD void bounce_pre_trace(const KParams& P, LaneCtx& c, WaveRange& wr, const bool
             // measured cost of a tile (orders the tiles of the next frame, hjr_cost_hist_kernel): a lane sums the rays of its
             // consecutive items of one tile and flushes when it moves on; lanes leaving the same tile together (the usual
             // case) share one atomic.  All lanes are here (m is wave-uniform), so the shuffles below are well defined.
-            const uint32_t old_tile = hjr_tile_id(HJR_PX(c) / HJR_TILE, HJR_PY(c) / HJR_TILE, P.tiles_x);
+            const uint32_t old_tile = hjr_tile_id(HJR_PX(c) / HJR_TILE, HJR_PY(c) / HJR_TILE, tiles_x);
             uint32_t new_tile = 0xffffffffu;
-            if (need && q < P.n_owned_items) new_tile = P.tile_order ? P.tile_order[(q >> 6) / P.n_chunks] : ((q >> 6) / P.n_chunks) * P.world + P.rank;
-            bool flush = need && P.tile_cost && c.it_cost != 0u && new_tile != old_tile;
+            if (need && q < n_owned_items) new_tile = tile_order ? tile_order[(q >> 6) / n_chunks] : ((q >> 6) / n_chunks) * world + HJR_COLD(rank);
+            bool flush = need && tile_cost && c.it_cost != 0u && new_tile != old_tile;
             while (__ballot(flush)) {
                 const int leader = __ffsll((long long)__ballot(flush)) - 1;
                 const uint32_t t = (uint32_t)__shfl((int)old_tile, leader);
                 const bool mine = flush && old_tile == t;
                 uint32_t v = mine ? c.it_cost : 0u;
                 for (int off = 32; off > 0; off >>= 1) v += (uint32_t)__shfl_xor((int)v, off);
-                if ((int)lane == leader) atomicAdd(&P.tile_cost[t / P.world], v);
+                if ((int)lane == leader) atomicAdd(&tile_cost[t / world], v);
                 if (mine) { c.it_cost = 0u; flush = false; }
             }
             if (need) {
-                if (q < P.n_owned_items) {
+                if (q < n_owned_items) {
                     // item q = ((owned tile * n_chunks) + chunk) * 64 + pixel-in-tile: the 64 lanes of a wave start on one
                     // tile and one sample chunk (coherent primary rays)
                     const uint32_t tc = q >> 6;
                     const uint32_t tile = new_tile;
-                    const uint32_t chunk = tc % P.n_chunks;
+                    const uint32_t chunk = tc % n_chunks;
                     uint32_t tx, ty;
-                    hjr_tile_xy(tile, P.tiles_x, &tx, &ty);
+                    hjr_tile_xy(tile, tiles_x, &tx, &ty);
                     const uint32_t px = tx * HJR_TILE + (q & 7u);
                     const uint32_t py = ty * HJR_TILE + ((q >> 3) & 7u);
                     if (px < P.width && py < P.height) {

@@ -248,6 +248,7 @@ extern "C" int hjr_render_file(const char* render_option_json, int device)
     hjr_scene_view view;
     HJR_INIT(view);
     hjr_scene_get_view(scene, &view);
+    if (opt.force_rebuild) (void)hjr_set_option(ctx, "force_rebuild", 1);
     rc = hjr_upload_scene(ctx, &view);
     if (rc == HJR_OK) { // setLUT (renderer.h:854-898); a missing LUT file only matters if a material uses it
         uint8_t* lut = nullptr;

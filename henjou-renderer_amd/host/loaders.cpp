@@ -130,6 +130,7 @@ bool load_render_option(const std::string& path, hjr_render_option& o, std::stri
             auto flag = [&](const char* k) { const Json* v = h->find(k); return v ? (v->is_bool() ? v->as_bool() : v->as_number() != 0.0) : false; };
             o.serial_io = flag("serial_io") ? 1 : 0;
             o.fast_math = flag("fast_math") ? 1 : 0;
+            o.force_rebuild = flag("force_rebuild") ? 1 : 0;
         }
     } catch (std::exception& e) { // :222-225
         err = std::string("Caught exception: ") + e.what();

@@ -135,6 +135,7 @@ typedef struct hjr_render_option {
     uint32_t tile;               /* shard granularity in pixels; 8 is the only supported value */
     int32_t serial_io;           /* default 0; 1: hjr_render_file renders, writes and prepares the next frame one after the other (no overlap) */
     int32_t fast_math;           /* default 0; 1: hjr_render_file / henjou_cli launch with HJR_FLAG_FAST_MATH */
+    int32_t force_rebuild;       /* default 0; 1: hjr_render_file rebuilds the frame data every frame even when nothing moved (benchmarking) */
 } hjr_render_option;
 
 typedef struct hjr_camera {      /* Params.camera_* (renderer/renderer.h:1187-1191) */

@@ -25,6 +25,7 @@ int hjr_commit_transforms(hjr_ctx*) { return HJR_ERR_DEVICE; }
 int hjr_render(hjr_ctx*, const hjr_params*, float*, float*, float*) { return HJR_ERR_DEVICE; }
 int hjr_render_denoised(hjr_ctx*, const hjr_params*, int, float*, uint32_t, uint32_t) { return HJR_ERR_DEVICE; }
 int hjr_get_stats(hjr_ctx*, hjr_stats*) { return HJR_ERR_DEVICE; }
+int hjr_set_option(hjr_ctx*, const char*, int) { return HJR_ERR_DEVICE; }
 }
 
 #define CHECK(c) do { if (!(c)) { fprintf(stderr, "CHECK failed: %s (line %d): %s\n", #c, __LINE__, hjr_last_error()); return 1; } } while (0)

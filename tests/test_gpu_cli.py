@@ -76,3 +76,25 @@ def test_cli_rank_process_path_on_one_gpu(tmp_path):
     assert q.returncode == 0, q.stdout + q.stderr
     assert (work / "b_001.png").read_bytes() == single
     assert "render + gather + assemble" in q.stderr
+
+
+def test_cli_launcher_stops_the_job_when_a_rank_fails(tmp_path):
+    """--devices 2 on a box with ONE GPU: rank 1 cannot create its context (device ordinal out of range) and exits, rank 0 is set up and
+    would wait for its peer inside ncclCommInitRank for ever.  The launcher must notice the failed child, stop the other and exit 1 —
+    round 2's launcher waited for its children in order and hung with the GPU held."""
+    import time
+    import torch
+    if torch.cuda.device_count() != 1:
+        pytest.skip("needs a box with exactly one GPU")
+    work = tmp_path / "run"
+    shutil.copytree(os.path.join(hjr.ASSETS, "Model"), work / "Model")
+    ro = json.load(open(os.path.join(hjr.ASSETS, "render_option_c1.json")))
+    ro["Image"].update(image_width=64, image_height=64, max_spp=4, image_name="never")
+    ro["Animation"].update(start_frame=1, end_frame=2)
+    (work / "render_option.json").write_text(json.dumps(ro))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    t0 = time.time()
+    p = subprocess.run([CLI, "render_option.json", "--devices", "2"], cwd=work, capture_output=True, text=True, timeout=120, env=env)
+    assert p.returncode == 1, (p.returncode, p.stderr[-1500:])
+    assert time.time() - t0 < 60
+    assert "stopping the others" in p.stderr and not (work / "never_001.png").exists()

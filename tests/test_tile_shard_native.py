@@ -69,3 +69,17 @@ def test_tile_ids_partition_the_frame_and_run_along_diagonals(w, h, n):
     inside = packed[..., 3] == 1.0
     xs, ys = packed[..., 0][inside].astype(np.int64), packed[..., 1][inside].astype(np.int64)
     assert masks[r][ys, xs].all() and inside.sum() == masks[r].sum()
+
+
+def test_cli_launcher_propagates_rank_failures_without_a_gpu(tmp_path):
+    """The multi-GPU launcher of henjou_cli (fork + exec of one rank process per GPU, RCCL id over inherited pipes): when the ranks fail
+    before they meet — here: the config does not exist, so no rank gets as far as a GPU call — the launcher reaps them, reports and exits 1
+    instead of waiting for ever.  Host-only: runs on the CPU box."""
+    cli = os.path.join(hjr.PKG_DIR, "henjou_cli")
+    assert os.path.exists(cli), "henjou_cli is not built (python __graft_entry__.py)"
+    p = subprocess.run([cli, str(tmp_path / "missing.json"), "--devices", "3"], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 1, (p.returncode, p.stderr[-800:])
+    assert "not found" in p.stderr and "stopping the others" in p.stderr
+    # a rank process started by hand without its pipe is refused, not run
+    q = subprocess.run([cli, str(tmp_path / "missing.json"), "--rank", "1", "--world", "2"], capture_output=True, text=True, timeout=60)
+    assert q.returncode == 2

@@ -14,8 +14,14 @@ json.dump(ro, open(w + '/render_option.json', 'w'))
 PY
 cd $W
 for mode in 1 0; do
-  echo "HJR_SERIAL_IO=$mode"
-  HJR_SERIAL_IO=$mode timeout -k 10 300 $R/henjou-renderer_amd/henjou_cli render_option.json 2>&1 | grep -E "wall|frame 1:|error" 
+  python3 - "$mode" <<'PY'
+import json, sys
+ro = json.load(open('render_option.json'))
+ro['Henjou_HIP'] = {'serial_io': sys.argv[1] == '1'}
+json.dump(ro, open('render_option.json', 'w'))
+PY
+  echo "serial_io=$mode"
+  timeout -k 10 300 $R/henjou-renderer_amd/henjou_cli render_option.json 2>&1 | grep -E "wall|frame 1:|error" 
   md5sum cornelbox_c2_00*.png | md5sum
 done
 rm -rf $W

@@ -15,7 +15,13 @@ json.dump(ro, open(w + '/render_option.json', 'w'))
 PY
 cd $W
 for mode in 1 0; do
-  echo "HJR_SERIAL_IO=$mode (forced rebuild every frame)"
-  HJR_FORCE_REBUILD=1 HJR_SERIAL_IO=$mode timeout -k 10 300 $R/henjou-renderer_amd/henjou_cli render_option.json 2>&1 | grep -E "wall|frame 2:|error"
+  python3 - "$mode" <<'PY'
+import json, sys
+ro = json.load(open('render_option.json'))
+ro['Henjou_HIP'] = {'serial_io': sys.argv[1] == '1', 'force_rebuild': True}
+json.dump(ro, open('render_option.json', 'w'))
+PY
+  echo "serial_io=$mode (forced rebuild every frame)"
+  timeout -k 10 300 $R/henjou-renderer_amd/henjou_cli render_option.json 2>&1 | grep -E "wall|frame 2:|error"
 done
 rm -rf $W

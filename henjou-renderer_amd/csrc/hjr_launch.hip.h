@@ -214,7 +214,7 @@ template <int I, bool S> int hjr_launch(hjr_ctx* c, const KParams& kp_in, uint64
     }
     if (lds_mode == 1) return launch_lds<I, S, false>(c, kp, n_items, st);
     if (lds_mode == 2) return launch_lds<I, S, true>(c, kp, n_items, st);
-    if (lds_mode == 3) return launch_mem<I, S, 2>(c, kp, n_items, st); // BVH2 read from memory (HJR_BVH_WIDTH=2 knob on a big scene)
+    if (lds_mode == 3) return launch_mem<I, S, 2>(c, kp, n_items, st); // BVH2 read from memory (option "bvh_width" = 2 on a big scene)
     return launch_mem<I, S, 4>(c, kp, n_items, st);
 #endif
 }

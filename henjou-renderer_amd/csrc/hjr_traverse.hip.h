@@ -65,7 +65,7 @@ HDH uint32_t stack_dec(uint16_t r16)
 // buffer ([level][lane], coalesced when neighbouring lanes overflow together).  The exact worst-case depth of a BVH4 over a
 // million triangles is ~46 entries, traversal rarely needs more than a dozen: with the whole stack in LDS the stacks, not the
 // registers, capped the occupancy at 3 workgroups per CU.  lds_n is a launch parameter (wave-uniform, an SGPR compare):
-// HJR_SHORT_STACK entries unless the environment overrides it (tests force the overflow path with HJR_SHORT_STACK=2).
+// HJR_SHORT_STACK entries unless option "short_stack" overrides it (tests force the overflow path with 2).
 #ifndef HJR_SHORT_STACK
 #define HJR_SHORT_STACK 16
 #endif

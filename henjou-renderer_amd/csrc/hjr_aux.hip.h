@@ -16,7 +16,7 @@ __global__ void __launch_bounds__(64) hjr_classify_tiles_kernel(const KParams P)
     typedef LaneStack<uint32_t, 64, false> ST;
     ST stack;
     stack.lds = reinterpret_cast<uint32_t*>(hjr_smem) + threadIdx.x;
-    stack.spill = nullptr; stack.spill_stride = 0; stack.lds_n = 0; stack.n_over = 0;
+    stack.spill = nullptr; stack.spill_stride = 0; stack.lds_n = 0; stack.n_over = 0; stack.top = nullptr; stack.n_top = 0u;
     uint32_t n_cls[4] = { 0u, 0u, 0u, 0u }; // per block; one atomic per class at the end (32 k atomics on four words cost 0.4 ms)
     for (uint32_t idx = blockIdx.x; idx < P.n_owned_tiles; idx += gridDim.x) {
         const uint32_t tile = idx * P.world + P.rank;

@@ -670,12 +670,19 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
     stack.spill = P.stack_spill + (blockIdx.x * BLOCK + threadIdx.x);
     stack.spill_stride = P.spill_stride;
     stack.lds_n = (int)P.stack_lds_entries;
+    stack.top = nullptr; stack.n_top = 0u;
     const uint32_t lane = threadIdx.x & 63u;
     const float4* nodes = P.nodes;
     const float4* tris = P.tri_geom;
     const float4* mats = P.materials;
     const float4* lights = P.lights;
     if (LDSBVH) stage_scene_in_lds<SE, BLOCK>(P, hjr_smem + (BLOCK * P.stack_depth * (uint32_t)sizeof(SE) + 15u) / 16u, nodes, tris, mats, lights);
+    else if (WIDTH == 4 && P.n_top_nodes) { // memory layout: the top of the (breadth-first) BVH4 behind the short stacks
+        float4* top = hjr_smem + (BLOCK * P.stack_lds_entries * (uint32_t)sizeof(SE) + 15u) / 16u;
+        for (uint32_t i = threadIdx.x; i < P.n_top_nodes * HJR_NODE4_F4; i += BLOCK) top[i] = P.nodes[i];
+        __syncthreads();
+        stack.top = top; stack.n_top = P.n_top_nodes;
+    }
 
     unsigned long long lc[HJR_NSTAT];
     if (STATS) for (int i = 0; i < HJR_NSTAT; i++) lc[i] = 0;

@@ -175,6 +175,9 @@ template <int I, bool S> static int launch_wf(hjr_ctx* c, const KParams& kp, uin
 #ifndef HJR_NODE_MIN_MEM
 #define HJR_NODE_MIN_MEM 24    /* scenes read from memory (1 M triangles, 1 / 8 / 16 / 24 / 32: megakernel 280 / 197 / 180 / 179 / 190 ms, wavefront 255 / 213 / 194 / 189 / 192) */
 #endif
+#ifndef HJR_TOP_NODES
+#define HJR_TOP_NODES 85 /* memory layouts, BVH4: nodes of the top of the tree (levels 0 - 3) staged in LDS per workgroup (option "top_nodes"; 1 M triangles, 0 / 21 / 85 / 140 / 200 / 341: 166.9 / 165.9 / 164.6 / 164.5 / 164.6 / 273.7 ms — the last one loses a workgroup per CU) */
+#endif
 #ifndef HJR_HOLD_MIN
 #define HJR_HOLD_MIN 8 /* megakernel: lanes of the rare material class (multiple-scattering GGX) a wave collects before it shades them (0: never hold; C2 with AOVs, 0 / 4 / 8 / 16 / 32: 129.0 / 126.5 / 126.2 / 127.9 / 144.2 ms) */
 #endif
@@ -203,8 +206,8 @@ template <int I, bool S> int hjr_launch(hjr_ctx* c, const KParams& kp_in, uint64
     kp.node_min = nm_forced ? nm_forced : (lds_layout ? (wf ? HJR_NODE_MIN_LDS_WF : HJR_NODE_MIN_LDS) : HJR_NODE_MIN_MEM);
 #ifdef HJR_LEAN_VARIANT /* kernel experiments (make variant X="-DHJR_LEAN_VARIANT ..."): only the LDS-resident megakernel is instantiated: builds in seconds */
     c->stats.pipeline = 0u;
-    if (!nm_forced) kp.node_min = HJR_NODE_MIN_LDS;
-    return lds_mode == 1 ? launch_lds<I, S, false>(c, kp, n_items, st) : -1;
+    if (!nm_forced) kp.node_min = lds_layout ? HJR_NODE_MIN_LDS : HJR_NODE_MIN_MEM;
+    return lds_mode == 1 ? launch_lds<I, S, false>(c, kp, n_items, st) : (lds_mode == 0 ? launch_mem<I, S, 4>(c, kp, n_items, st) : -1);
 #else
     if (wf) {
         const int rc = launch_wf<I, S>(c, kp, n_items, lds_mode, st);
@@ -227,7 +230,14 @@ template <int I, bool S, int W, int A> static int launch_mem2(hjr_ctx* c, const 
 {
     const uint32_t short_stack = (uint32_t)c->opt.get(hjr::OPT_SHORT_STACK, HJR_SHORT_STACK); // tests force the overflow path with 2
     const uint32_t lds_entries = kp.stack_depth < short_stack ? kp.stack_depth : short_stack;
-    const size_t smem = (size_t)HJR_BLOCK * lds_entries * 4;
+    // BVH4: the top of the tree (breadth-first ids: the first nodes) in LDS next to the stacks; sized so that four workgroups still share a CU
+    uint32_t n_top = 0;
+    if (W == 4) {
+        const uint32_t want = (uint32_t)c->opt.get(hjr::OPT_TOP_NODES, HJR_TOP_NODES);
+        const uint32_t have = kp.n_node_f4 / HJR_NODE4_F4;
+        n_top = want < have ? want : have;
+    }
+    const size_t smem = (((size_t)HJR_BLOCK * lds_entries * 4 + 15) / 16) * 16 + (size_t)n_top * HJR_NODE4_F4 * 16;
     auto kern = hjr_render_kernel<I, S, HJR_BLOCK, false, false, W, A, HJR_FAST_TAG>;
     int per_cu = 0;
     if (c->opt.is_set(hjr::OPT_BLOCKS_PER_CU)) per_cu = c->opt.get(hjr::OPT_BLOCKS_PER_CU, 0);
@@ -247,7 +257,9 @@ template <int I, bool S, int W, int A> static int launch_mem2(hjr_ctx* c, const 
     }
     k2.stack_spill = (uint32_t*)c->d_spill.p;
     k2.stack_lds_entries = lds_entries;
+    k2.n_top_nodes = n_top;
     c->stats.stack_lds_entries = lds_entries;
+    if (smem > 48 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return -1;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(HJR_BLOCK), smem, st, k2);
     return 0;
 }

@@ -46,6 +46,7 @@ struct KParams {
     uint32_t* cost_hist;             // [0..63] tiles per cost bucket, [64..127] scatter cursors
     uint32_t cost_div;               // 64 * spp: rays per tile at one ray per sample
     uint32_t spill_stride;           // lanes in the grid
+    uint32_t n_top_nodes;            // memory-path megakernel, BVH4: nodes [0, n_top_nodes) are also staged in LDS by every workgroup (0: none)
     uint32_t stack_lds_entries;      // memory-path kernels: stack entries per lane kept in LDS (the rest overflow to stack_spill)
     uint32_t node_min;               // descent loop of the fused traversals: lanes still holding an inner node below which a pass moves on to the leaves (hjr_traverse.hip.h)
     uint32_t hold_min, hold_age;     // megakernel: hits of the rare material class wait until a wave has hold_min of them or one has waited hold_age rounds (0: off)

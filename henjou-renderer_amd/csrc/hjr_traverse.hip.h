@@ -72,6 +72,11 @@ HDH uint32_t stack_dec(uint16_t r16)
 template <typename E, int BLOCK_, bool SPILL, bool COUNT = false, bool NLDS = false>
 struct LaneStack {
     static constexpr bool kNodesInLds = NLDS; // the kernel stages nodes (and triangles) in LDS: node addresses are 32-bit LDS addresses
+    static constexpr bool kSpill = SPILL;
+    // memory layouts (SPILL): the first n_top nodes of the breadth-first BVH4 — the top of the tree, which every ray walks — are also staged in
+    // LDS by the workgroup (`top`); node_step reads a node from there when its id is below n_top (0: no copy)
+    const float4* top;
+    uint32_t n_top;
     E* lds;
     uint32_t* spill;
     uint32_t spill_stride;
@@ -183,6 +188,7 @@ HD uint32_t node_step(const float4* nodes, uint32_t& cur, const BoxRay<WIDTH, ST
     return 2u;
     } else {
     const float4* nd = nodes + cur * HJR_NODE4_F4;
+    if constexpr (ST::kSpill) { if (cur < stack.n_top) nd = stack.top + cur * HJR_NODE4_F4; } // top of the tree: LDS copy (flat loads serve both)
     const f3 inv = R.inv, oi = R.oi;
     const float INF = bits2f(0x7f800000u);
     // near / far plane rows picked by the ray's direction signs: no min/max per axis

@@ -305,8 +305,8 @@ HD void wf_trace_stage(const KParams& P, WfShared* Q, wf_ring_ptr rings, const f
             ro = V(n0.x, n0.y, n0.z); db = V(n0.w, n1.x, n1.y); a_tmax = n1.z;
             b_valid = flags & WF_TRACING; fresh = flags & WF_FRESH;
             occluded = false;
-            hit.prim = 0xffffffffu; hit.t = 1e16f;
             phase = (flags & WF_SH_VALID) ? 0 : 1; // a queued context has at least one of the two rays
+            hit.prim = 0xffffffffu; hit.t = (phase == 0) ? a_tmax : 1e16f; // hit.t = far end of the ray being traced (as in traverse_fused)
             o = (phase == 0 || !fresh) ? ro : cam_o;
             d = (phase == 0) ? V(n2.x, n2.y, n2.z) : db;
             R = box_ray<WIDTH, ST::kNodesInLds>(nodes, o, d);
@@ -339,8 +339,7 @@ HD void wf_trace_stage(const KParams& P, WfShared* Q, wf_ring_ptr rings, const f
             for (;;) { // every lane first descends through inner nodes until it holds a leaf (or is out of work) ...
                 if (!(cur & HJR_LEAF_FLAG)) {
                     WF_T(11, 1); WF_T(12, __popcll(__ballot(true)));
-                    const float tfar = (phase == 0) ? a_tmax : hit.t;
-                    const uint32_t nb = node_step<WIDTH, BLOCK, ST>(nodes, cur, R, tmin, tfar, stack, sp);
+                    const uint32_t nb = node_step<WIDTH, BLOCK, ST>(nodes, cur, R, tmin, hit.t, stack, sp);
                     if (STATS) { if (phase == 0) lc[5] += nb; else lc[3] += nb; }
                 }
                 // ... or until fewer than P.node_min lanes are still descending: those keep their node for the next pass
@@ -375,6 +374,7 @@ HD void wf_trace_stage(const KParams& P, WfShared* Q, wf_ring_ptr rings, const f
                 if (STATS) { if (phase == 0) lc[2] += 1; else lc[1] += 1; }
                 if (phase == 0 && b_valid) { // this lane's shadow ray is resolved: start its closest-hit ray right away
                     phase = 1;
+                    hit.t = 1e16f;
                     o = fresh ? cam_o : ro; d = db;
                     R = box_ray<WIDTH, ST::kNodesInLds>(nodes, o, d);
                     sp = 0; cur = 0;
@@ -446,6 +446,7 @@ __global__ void __launch_bounds__(BLOCK, 1) hjr_wavefront_kernel(const KParams P
     stack.spill = P.stack_spill + (blockIdx.x * BLOCK + threadIdx.x);
     stack.spill_stride = P.spill_stride;
     stack.lds_n = (int)P.stack_lds_entries;
+    stack.top = nullptr; stack.n_top = 0u;
     const uint32_t lane = threadIdx.x & 63u;
     const float4* nodes = P.nodes;
     const float4* tris = P.tri_geom;

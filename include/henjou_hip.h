@@ -280,6 +280,7 @@ int hjr_get_stats(hjr_ctx*, hjr_stats* out);
  *   "hold_age"        1..1000     ... or rounds the oldest of them has waited (2)
  *   "short_stack"     1..64       memory layouts: traversal-stack entries per lane kept in LDS, deeper ones overflow to HBM (16)
  *   "blocks_per_cu"   1..8        memory layouts: workgroups per CU of the persistent grid (occupancy query)
+ *   "top_nodes"       0..1024     memory layouts, BVH4: nodes of the top of the tree every workgroup also keeps in LDS (85 = levels 0 - 3; 0 none)
  *   "tile_order"      0 1 2       0 plain tile order, 1 first-hit classes, 2 classes + measured cost of the previous frame (1 on one GPU, 2 when sharded)
  *   "wf_cap"          64..32768   wavefront kernel: path contexts per workgroup, a power of two (2048 in LDS layouts, 4096 otherwise)
  *   "wf_refill" / "wf_prefetch_min" / "wf_trace_min"   wavefront kernel: hand-over thresholds of the trace stage, scheduler preference

@@ -394,7 +394,14 @@ def main():
                     "sq_active_inst_any_frac": c["SQ_ACTIVE_INST_ANY"] / max(c["SQ_WAVE_CYCLES"], 1.0),
                     "sq_wait_inst_any_frac": c["SQ_WAIT_INST_ANY"] / max(c["SQ_WAVE_CYCLES"], 1.0)}
 
-        roof = {"kernel": "hjr_render_kernel / hjr_wavefront_kernel + hjr_finalize_kernel + tile pre-pass (%s, 3 AOVs); rocprof names in profiles/r03_kernel_stats.csv" % args.integrator, "kernel_ms_avg": round(avg_ms, 3),
+        # the dominant kernel under the name rocprofv3 prints for it (template arguments: integrator, counting, block, scene in LDS, 16-bit stack,
+        # BVH width, variant 1 = with albedo / normal sums[, fast-math tag]); the other kernels of a step: hjr_finalize_kernel + the tile pre-pass
+        lm = st["lds_mode"]
+        if pipe_full == "persistent megakernel":
+            kname = "void hjr_render_kernel<%d, false, %d, %s, %s, %d, 1, false>(KParams)" % (integ, 1024 if lm in (1, 2) else 256, "true" if lm in (1, 2) else "false", "true" if lm == 2 else "false", 4 if lm == 0 else 2)
+        else:
+            kname = "void hjr_wavefront_kernel<%d, false, 1024, %s, %s, %d, 1>(KParams)" % (integ, "true" if lm in (1, 2) else "false", "true" if (lm not in (1, 2) or st["stack_lds_entries"] < st["stack_need"]) else "false", 4 if lm == 0 else 2)
+        roof = {"kernel": kname, "kernel_note": "%s, 3 AOVs; avg duration of this name in profiles/r03_kernel_stats.csv" % args.integrator, "kernel_ms_avg": round(avg_ms, 3),
                 "kernel_Msamples_per_s": round(samples_per_launch / (avg_ms * 1e-3) / 1e6, 3),
                 "pipeline": pipe_full,
                 "algorithmic": {"bytes_per_sample": round(bps, 1), "GBps": round(algorithmic_gbs, 2),

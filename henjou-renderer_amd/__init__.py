@@ -147,6 +147,7 @@ def lib():
             "hjr_render_device": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
             "hjr_synchronize": [C.c_void_p],
             "hjr_get_stats": [C.c_void_p, C.c_void_p],
+            "hjr_preview_device": [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p],
             "hjr_set_option": [C.c_void_p, C.c_char_p, C.c_int],
             "hjr_get_option": [C.c_void_p, C.c_char_p, C.c_void_p],
             "hjr_float4_to_srgb8": [C.c_void_p, C.c_void_p, C.c_uint32],
@@ -418,6 +419,11 @@ class Device:
 
     def synchronize(self):
         _check(lib().hjr_synchronize(self._h), "hjr_synchronize")
+
+    def preview_device(self, d_color, width, height, tonemap, d_rgba8, stream=None):
+        """hjr_preview_device: the raygen's 8-bit preview image from a float4 colour image, device pointers (ints)."""
+        _check(lib().hjr_preview_device(self._h, C.c_void_p(d_color), width, height, tonemap, C.c_void_p(d_rgba8),
+                                        C.c_void_p(stream) if stream else None), "hjr_preview_device")
 
     def set_option(self, key, value):
         """hjr_set_option: tuning / test option of this context (-1 restores the default); layout options act at the next set_transforms."""

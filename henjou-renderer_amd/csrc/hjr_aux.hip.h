@@ -156,3 +156,46 @@ __global__ void __launch_bounds__(256) hjr_unpack_tiles_kernel(const float4* pac
     const uint32_t x = tx * HJR_TILE + ((uint32_t)sl & 7u), y = ty * HJR_TILE + (((uint32_t)sl >> 3) & 7u);
     if (x < width && y < height) frame[(size_t)y * width + x] = packed[sl];
 }
+
+// ---- the 8-bit preview buffer of the raygen program (`uchar4* image` of Params, renderer/renderer.h:1102, 1175: written by the missing
+// __raygen__rg, never read back by the host — the PNG comes from AOV_Output).  Build-defined: the colour AOV through the tonemappers of
+// kernel/color.h (Tonemap_Uchimura :10-39, ACESFilm :55-63), then toSRGB + quantizeUnsignedChar as float4ConvertColor does on the host
+// (renderer.h:73-101).  The host form is hjr_tonemap_to_srgb8 (libm); this one uses the device's pow / exp, so single pixels may differ by
+// one code value at a quantisation boundary.
+__device__ inline float hjr_tm_uchimura(float x)
+{
+    const float P = 1.0f, a = 1.0f, m = 0.22f, l = 0.4f, c = 1.33f, b = 0.0f;
+    const float l0 = ((P - m) * l) / a, S0 = m + l0, S1 = m + a * l0, C2 = (a * P) / (P - S1), CP = -C2 / P;
+    const float sx = fmaxf(0.0f, fminf((x - 0.0f) / (m - 0.0f), 1.0f));
+    const float w0 = (float)(1.0 - (double)(sx * sx * (3.0f - 2.0f * sx)));
+    const float w2 = (float)((m + l0) < x);
+    const float w1 = (float)(1.0 - (double)w0 - (double)w2);
+    const float T = (float)((double)m * pow((double)(x / m), (double)c) + (double)b);
+    const float S = (float)((double)P - (double)(P - S1) * exp((double)(CP * (x - S0))));
+    const float L = m + a * (x - m);
+    return T * w0 + L * w1 + S * w2;
+}
+__device__ inline float hjr_tm_aces(float x)
+{
+    const float a = 2.51f, b = 0.03f, c = 2.43f, d = 0.59f, e = 0.14f;
+    return fmaxf(0.0f, fminf((x * (a * x + b)) / (x * (c * x + d) + e), 1.0f));
+}
+__global__ void __launch_bounds__(256) hjr_preview_kernel(const float4* color, uchar4* out, size_t n, int tonemap)
+{
+    const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float4 v = color[i];
+    float ch[3] = { v.x, v.y, v.z };
+    unsigned char q8[3];
+    for (int k = 0; k < 3; k++) {
+        float col = ch[k];
+        col = tonemap == 1 ? hjr_tm_uchimura(col) : (tonemap == 2 ? hjr_tm_aces(col) : col);
+        const float powed = powf(col, 1.0f / 2.4f);
+        const float sr = col < 0.0031308f ? 12.92f * col : 1.055f * powed - 0.055f;
+        const float q = sr * 256.0f;
+        const uint32_t u = (q > 0.0f) ? ((q >= 4294967040.0f) ? 4294967040u : (uint32_t)q) : 0u;
+        q8[k] = (unsigned char)(u < 255u ? u : 255u);
+    }
+    out[i] = make_uchar4(q8[0], q8[1], q8[2], 255);
+}
+

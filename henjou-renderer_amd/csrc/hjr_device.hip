@@ -658,6 +658,17 @@ extern "C" int hjr_unpack_tiles_device(hjr_ctx* c, const void* d_packed, uint32_
     return HJR_OK;
 }
 
+extern "C" int hjr_preview_device(hjr_ctx* c, const void* d_color, uint32_t w, uint32_t h, int tonemap, void* d_rgba8, void* hip_stream)
+{
+    if (!c || !d_color || !d_rgba8 || w == 0 || h == 0 || tonemap < HJR_TONEMAP_NONE || tonemap > HJR_TONEMAP_ACES) { set_error("hjr_preview_device: bad argument"); return HJR_ERR_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    const size_t n = (size_t)w * h;
+    hipLaunchKernelGGL(hjr_preview_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float4*)d_color, (uchar4*)d_rgba8, n, tonemap);
+    HIPCHK(hipGetLastError());
+    return HJR_OK;
+}
+
 extern "C" int hjr_synchronize(hjr_ctx* c)
 {
     if (!c) { set_error("hjr_synchronize: null context"); return HJR_ERR_ARG; }

@@ -265,6 +265,11 @@ int hjr_render_denoised(hjr_ctx*, const hjr_params*, int render_mode, float* out
 /* the same on device pointers (float4 images), asynchronous on `hip_stream` (NULL = the context's stream) */
 int hjr_denoise_device(hjr_ctx*, int render_mode, uint32_t in_w, uint32_t in_h, const void* d_color, const void* d_albedo,
                        const void* d_normal, void* d_out, uint32_t out_w, uint32_t out_h, void* hip_stream);
+/* The 8-bit preview buffer of the raygen program — `uchar4* image` of Params, allocated at renderer/renderer.h:1102 and bound at :1175, written
+ * by the missing __raygen__rg and never read back by the host.  Build-defined: a float4 colour image on the device -> tonemapper of kernel/color.h
+ * (HJR_TONEMAP_*) -> toSRGB + quantise (renderer.h:73-101) -> width*height RGBA8 on the device; asynchronous on `hip_stream` (NULL = the
+ * context's stream).  The host form is hjr_tonemap_to_srgb8; device pow / exp may differ from libm by one code value at a quantisation boundary. */
+int hjr_preview_device(hjr_ctx*, const void* d_color, uint32_t width, uint32_t height, int tonemap, void* d_rgba8, void* hip_stream);
 int hjr_get_stats(hjr_ctx*, hjr_stats* out);
 /* Tuning / test options of a context.  The library reads NO environment variable: kernel selection and layouts depend on the scene, the
  * launch parameters and these options only.  value -1 = the library's default; HJR_ERR_ARG for an unknown key or a value out of range.

@@ -245,3 +245,34 @@ def test_frame_from_the_product_loader_equals_oracle_on_an_independent_reading_o
             assert_bitexact(normal, on, "aov_normal")
     finally:
         d.close()
+
+
+def test_preview_buffer_on_the_device():
+    """hjr_preview_device: the raygen's `uchar4 image` (renderer.h:1102, 1175) — the colour AOV through a tonemapper of kernel/color.h and the sRGB /
+    quantise stage, on the device.  Against the host form of the same arithmetic (hjr_tonemap_to_srgb8, libm): equal, but for single pixels one
+    code value off where the device's pow / exp rounds differently right at a quantisation boundary."""
+    import torch
+    s = Cornell()
+    d = s.device()
+    try:
+        w, h = 200, 120
+        fb = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+        d.render_device(s.hjr_params(w, h, 16), fb.data_ptr())
+        d.synchronize()
+        host_in = fb.cpu().numpy()
+        ramp = torch.linspace(0.0, 4.0, w * h, device="cuda").reshape(h, w)  # every code value and the shoulder of the tonemappers
+        fb2 = torch.stack([ramp, ramp * 0.5, ramp * ramp, torch.ones_like(ramp)], dim=-1).contiguous()
+        for img, name in ((fb, "frame"), (fb2, "ramp")):
+            for mode in (hjr.TONEMAP_NONE, hjr.TONEMAP_UCHIMURA, hjr.TONEMAP_ACES):
+                out = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+                d.preview_device(img.data_ptr(), w, h, mode, out.data_ptr())
+                d.synchronize()
+                got = out.cpu().numpy()
+                exp = hjr.tonemap_to_srgb8(img.cpu().numpy(), mode)
+                diff = np.abs(got.astype(np.int32) - exp.astype(np.int32))
+                assert diff.max() <= 1, (name, mode, int(diff.max()))
+                assert (diff != 0).mean() < 1e-3, (name, mode, float((diff != 0).mean()))
+                assert (got[..., 3] == 255).all()
+        assert np.isfinite(host_in).all()
+    finally:
+        d.close()

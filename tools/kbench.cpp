@@ -1,6 +1,6 @@
 // tools/kbench — kernel-variant bench over the C-ABI, no Python / torch start-up cost.
 //   kbench <libhenjou_hip.so> <render_option.json> [--width W] [--height H] [--spp S] [--integrator 0|1|2] [--reps N]
-//          [--aovs] [--rank r --world n] [--stats] [--fast]
+//          [--aovs] [--rank r --world n] [--stats] [--fast] [--opt key=value ...]
 // dlopens the given build of the library (so several builds can be compared inside one gpurun call), renders the start frame of
 // the config `reps` times through hjr_render (host buffers; the kernel time is the library's own HIP-event time around the
 // kernels) and prints kernel ms (min / mean), Msamples/s and an FNV-1a hash of the colour AOV (equal hashes = bit-identical
@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../include/henjou_hip.h"
@@ -25,13 +26,14 @@ int main(int argc, char** argv)
     if (!h) { fprintf(stderr, "kbench: %s\n", dlerror()); return 2; }
     SYM(hjr_last_error) SYM(hjr_load_render_option) SYM(hjr_scene_load_gltf) SYM(hjr_scene_get_view) SYM(hjr_scene_eval_transforms)
     SYM(hjr_scene_eval_camera) SYM(hjr_load_png_rgba8) SYM(hjr_free) SYM(hjr_create) SYM(hjr_upload_scene) SYM(hjr_set_transforms)
-    SYM(hjr_set_lut) SYM(hjr_render) SYM(hjr_get_stats) SYM(hjr_destroy)
+    SYM(hjr_set_lut) SYM(hjr_render) SYM(hjr_get_stats) SYM(hjr_destroy) SYM(hjr_set_option)
     hjr_render_option opt;
     HJR_INIT(opt);
 #define CHK(call) do { int rc_ = (call); if (rc_ != HJR_OK) { fprintf(stderr, "kbench: %s -> %d: %s\n", #call, rc_, p_hjr_last_error()); return 1; } } while (0)
     CHK(p_hjr_load_render_option(argv[2], &opt));
     int reps = 3, rank = 0, world = 1;
     bool aovs = false, stats = false, fast = false;
+    std::vector<std::pair<std::string, int>> options; // --opt key=value -> hjr_set_option (before the frame data is built)
     for (int i = 3; i < argc; i++) {
         std::string a = argv[i];
         auto val = [&]() { return (i + 1 < argc) ? atoi(argv[++i]) : 0; };
@@ -45,6 +47,7 @@ int main(int argc, char** argv)
         else if (a == "--aovs") aovs = true;
         else if (a == "--stats") stats = true;
         else if (a == "--fast") fast = true;
+        else if (a == "--opt" && i + 1 < argc) { std::string kv = argv[++i]; const size_t eq = kv.find('='); if (eq == std::string::npos) { fprintf(stderr, "kbench: --opt key=value\n"); return 2; } options.push_back({ kv.substr(0, eq), atoi(kv.c_str() + eq + 1) }); }
         else { fprintf(stderr, "kbench: unknown option %s\n", a.c_str()); return 2; }
     }
     hjr_scene* scene = nullptr;
@@ -54,6 +57,7 @@ int main(int argc, char** argv)
     CHK(p_hjr_scene_get_view(scene, &view));
     hjr_ctx* ctx = nullptr;
     CHK(p_hjr_create(0, &ctx));
+    for (auto& o : options) CHK(p_hjr_set_option(ctx, o.first.c_str(), o.second));
     CHK(p_hjr_upload_scene(ctx, &view));
     {
         uint8_t* lut = nullptr; int lw = 0, lh = 0;

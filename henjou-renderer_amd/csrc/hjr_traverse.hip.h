@@ -17,25 +17,34 @@ HD f3 crossf(f3 a, f3 b)
 {
     return V(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
 }
-// canonical ray/triangle test — the same operation sequence as the oracle's ray_tri().  The early returns stay: a
-// version without them (all seven conditions combined at the end) ran 2.5 % slower on the bundled scene (profiles/r03_experiments.md).
+// canonical ray/triangle test — the same operation sequence as the oracle's ray_tri().  Two shapes of the same arithmetic:
+// with early returns (EARLY; the megakernel on LDS-resident scenes: whole waves leave at the first two tests often enough, 2.5 % faster there) and
+// with all seven conditions evaluated and combined at the end (scenes read from memory and the wavefront kernels: the fewer branches the better,
+// 1.2 % / 0.8 % faster there).  A zero
+// determinant makes inv infinite and u infinite or NaN; `det != 0` keeps the result explicit.  (profiles/r03_experiments.md)
+template <bool EARLY_>
 HD bool ray_tri(f3 v0, f3 v1, f3 v2, f3 o, f3 d, float tmin, float tmax, float& t, float& b1, float& b2)
 {
+#ifdef HJR_EXP_TRI_EARLY_OFF
+    constexpr bool EARLY = false;
+#else
+    constexpr bool EARLY = EARLY_;
+#endif
     f3 e1 = v1 - v0, e2 = v2 - v0;
     f3 p = crossf(d, e2);
     float det = dotf(e1, p);
-    if (det == 0.0f) return false;
+    if (EARLY && det == 0.0f) return false;
     float inv = exact_div(1.0f, det); // == 1.0f / det, whatever the division flags of the translation unit
     f3 tv = o - v0;
     float u = dotf(tv, p) * inv;
-    if (!(u >= 0.0f && u <= 1.0f)) return false;
+    if (EARLY && !(u >= 0.0f && u <= 1.0f)) return false;
     f3 q = crossf(tv, e1);
     float v = dotf(d, q) * inv;
-    if (!(v >= 0.0f && u + v <= 1.0f)) return false;
+    if (EARLY && !(v >= 0.0f && u + v <= 1.0f)) return false;
     float tt = dotf(e2, q) * inv;
-    if (!(tt > tmin && tt < tmax)) return false;
-    t = tt; b1 = u; b2 = v;
-    return true;
+    const bool ok = (det != 0.0f) & (u >= 0.0f) & (u <= 1.0f) & (v >= 0.0f) & (u + v <= 1.0f) & (tt > tmin) & (tt < tmax);
+    if (ok) { t = tt; b1 = u; b2 = v; }
+    return ok;
 }
 
 // ---- per-lane traversal stack in LDS, element i of this lane at stack[i * BLOCK] (conflict-free columns).  Small scenes that
@@ -69,8 +78,9 @@ HDH uint32_t stack_dec(uint16_t r16)
 #ifndef HJR_SHORT_STACK
 #define HJR_SHORT_STACK 16
 #endif
-template <typename E, int BLOCK_, bool SPILL, bool COUNT = false, bool NLDS = false>
+template <typename E, int BLOCK_, bool SPILL, bool COUNT = false, bool NLDS = false, bool TRI_EARLY = NLDS>
 struct LaneStack {
+    static constexpr bool kTriEarly = TRI_EARLY; // which shape of ray_tri the kernel uses: early returns pay in the LDS-resident megakernel only
     static constexpr bool kNodesInLds = NLDS; // the kernel stages nodes (and triangles) in LDS: node addresses are 32-bit LDS addresses
     static constexpr bool kSpill = SPILL;
     // memory layouts (SPILL): the first n_top nodes of the breadth-first BVH4 — the top of the tree, which every ray walks — are also staged in
@@ -180,7 +190,7 @@ HD uint32_t node_step(const float4* nodes, uint32_t& cur, const BoxRay<WIDTH, ST
     const bool h0 = lo0 <= hi0, h1 = lo1 <= hi1; // conservative through the 2^-15 box padding (>= 16x the rounding error of t)
     const uint32_t c0 = cc.x, c1 = cc.y;
     // (the push stays a branch here: writing the farther child unconditionally and advancing the top by 0 / 1, as the BVH4 step below does,
-    // was measured 1 % slower on the LDS-resident scene — the LDS pipe is the busier one there)
+    // was measured slower for the BVH2 layouts — megakernel 118.8 -> 120.1 ms, MIS on the wavefront kernel 176.2 -> 179.6: the LDS pipe is the busier one)
     if (h0 && h1) {
         const bool swap = lo1 < lo0;
         stack.put(sp, swap ? c0 : c1);
@@ -254,7 +264,7 @@ HD bool traverse(const float4* nodes, const float4* tris, f3 o, f3 d, float tmin
             const float4 g0 = g[0], g1 = g[1], g2 = g[2];
             float t, b1, b2;
             if (STATS) cnt.tri++;
-            if (ray_tri(V(g0.x, g0.y, g0.z), V(g0.w, g1.x, g1.y), V(g1.z, g1.w, g2.x), o, d, tmin, tmax, t, b1, b2)) {
+            if (ray_tri<ST::kTriEarly>(V(g0.x, g0.y, g0.z), V(g0.w, g1.x, g1.y), V(g1.z, g1.w, g2.x), o, d, tmin, tmax, t, b1, b2)) {
                 if (ANY) return true;
                 const uint32_t prim = f2bits(g2.y);
                 // order-independent closest-hit rule: smaller t wins; equal t -> smaller global prim id
@@ -362,7 +372,7 @@ HD bool traverse_fused(const float4* nodes, const float4* tris, const bool a_val
                 const float4 g0 = g[0], g1 = g[1], g2 = g[2];
                 float t, b1, b2;
                 if (STATS) { if (phase == 0) ca.tri++; else cb.tri++; }
-                if (ray_tri(V(g0.x, g0.y, g0.z), V(g0.w, g1.x, g1.y), V(g1.z, g1.w, g2.x), o, d, tmin, tri_tmax, t, b1, b2)) {
+                if (ray_tri<ST::kTriEarly>(V(g0.x, g0.y, g0.z), V(g0.w, g1.x, g1.y), V(g1.z, g1.w, g2.x), o, d, tmin, tri_tmax, t, b1, b2)) {
                     if (phase == 0) { occluded = true; done = true; break; }
                     const uint32_t prim = f2bits(g2.y);
                     // order-independent closest-hit rule: smaller t wins; equal t -> smaller global prim id

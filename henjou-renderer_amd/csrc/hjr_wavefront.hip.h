@@ -356,7 +356,7 @@ HD void wf_trace_stage(const KParams& P, WfShared* Q, wf_ring_ptr rings, const f
                     const float4 g0 = g[0], g1 = g[1], g2 = g[2];
                     float t, b1, b2;
                     if (STATS) { if (phase == 0) lc[6] += 1; else lc[4] += 1; }
-                    if (ray_tri(V(g0.x, g0.y, g0.z), V(g0.w, g1.x, g1.y), V(g1.z, g1.w, g2.x), o, d, tmin, tri_tmax, t, b1, b2)) {
+                    if (ray_tri<ST::kTriEarly>(V(g0.x, g0.y, g0.z), V(g0.w, g1.x, g1.y), V(g1.z, g1.w, g2.x), o, d, tmin, tri_tmax, t, b1, b2)) {
                         if (phase == 0) { occluded = true; done = true; break; }
                         const uint32_t prim = f2bits(g2.y);
                         // order-independent closest-hit rule: smaller t wins; equal t -> smaller global prim id
@@ -439,7 +439,7 @@ __global__ void __launch_bounds__(BLOCK, 1) hjr_wavefront_kernel(const KParams P
 {
     constexpr bool AOVS = VAR >= 1, TEX = VAR == 2; // as in hjr_render_kernel
     typedef uint32_t SE;
-    typedef LaneStack<SE, BLOCK, SPILL, STATS, LDSBVH> ST;
+    typedef LaneStack<SE, BLOCK, SPILL, STATS, LDSBVH, false> ST; // (last: the branch-free shape of the triangle test)
     ST stack;
     stack.n_over = 0;
     stack.lds = reinterpret_cast<SE*>(hjr_smem) + threadIdx.x;

@@ -250,7 +250,6 @@ extern template int hjr_launch<HJR_INTEGRATOR_MIS, true>(hjr_ctx*, const KParams
 template <int I> int hjr_launch_fast(hjr_ctx*, const KParams&, uint64_t, int, hipStream_t); // hjr_launch_fast_*.hip (HJR_FLAG_FAST_MATH)
 extern template int hjr_launch_fast<HJR_INTEGRATOR_NEE>(hjr_ctx*, const KParams&, uint64_t, int, hipStream_t);
 extern template int hjr_launch_fast<HJR_INTEGRATOR_PT>(hjr_ctx*, const KParams&, uint64_t, int, hipStream_t);
-extern template int hjr_launch_fast<HJR_INTEGRATOR_MIS>(hjr_ctx*, const KParams&, uint64_t, int, hipStream_t);
 #define HJR_HAVE_FAST 1
 #endif
 #ifdef HJR_UNITY /* diagnostic variants (make variant): one translation unit, so that the __device__ diagnostic counters are one symbol */
@@ -418,10 +417,11 @@ static int render_impl(hjr_ctx* c, const hjr_params* p, void* d_color, void* d_a
     lrc = hjr_launch<HJR_INTEGRATOR_NEE, false>(c, kp, n_items, lds_mode, st);
 #else
 #ifdef HJR_HAVE_FAST
-    if ((p->flags & HJR_FLAG_FAST_MATH) && !stats) { // approximate-arithmetic kernels (megakernel family); a counting launch stays exact
+    // approximate-arithmetic kernels (megakernel family).  A counting launch stays exact, and so does MIS: its exact launch runs on the
+    // wavefront kernels, which beat the approximate megakernel (C2: 175 vs 185 ms), so the flag would only make it slower
+    if ((p->flags & HJR_FLAG_FAST_MATH) && !stats && p->integrator != HJR_INTEGRATOR_MIS) {
         c->stats.fast_math = 1u;
-        lrc = p->integrator == HJR_INTEGRATOR_NEE ? hjr_launch_fast<HJR_INTEGRATOR_NEE>(c, kp, n_items, lds_mode, st)
-            : (p->integrator == HJR_INTEGRATOR_PT ? hjr_launch_fast<HJR_INTEGRATOR_PT>(c, kp, n_items, lds_mode, st) : hjr_launch_fast<HJR_INTEGRATOR_MIS>(c, kp, n_items, lds_mode, st));
+        lrc = p->integrator == HJR_INTEGRATOR_NEE ? hjr_launch_fast<HJR_INTEGRATOR_NEE>(c, kp, n_items, lds_mode, st) : hjr_launch_fast<HJR_INTEGRATOR_PT>(c, kp, n_items, lds_mode, st);
     } else
 #endif
     switch (p->integrator * 2 + (stats ? 1 : 0)) {

@@ -167,7 +167,8 @@ typedef struct hjr_params {
                                   * multiply-adds in the SHADING code, as the reference's own build does (nvcc --use_fast_math: div.approx, sqrt.approx,
                                   * sin.approx in lib/ptx); traversal and ray / triangle test unchanged.  Frames are NOT bit-identical to the default
                                   * (exact) kernels: they agree within the metric's tolerance (per-pixel RMSE < 1e-3 at 1024 spp; tests/test_gpu_fast_math.py).
-                                  * Megakernel family only; ignored by HJR_FLAG_STATS launches. */
+                                  * Megakernel family only (NEE and Pathtrace); ignored by HJR_FLAG_STATS launches and by MIS launches, whose exact wavefront
+                                  * kernels are faster than an approximate megakernel would be (hjr_stats.fast_math tells what ran). */
 
 typedef struct hjr_stats {
     uint32_t struct_size;        /* sizeof(hjr_stats) of the caller (HJR_INIT) */

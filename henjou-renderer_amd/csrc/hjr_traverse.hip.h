@@ -22,14 +22,9 @@ HD f3 crossf(f3 a, f3 b)
 // with all seven conditions evaluated and combined at the end (scenes read from memory and the wavefront kernels: the fewer branches the better,
 // 1.2 % / 0.8 % faster there).  A zero
 // determinant makes inv infinite and u infinite or NaN; `det != 0` keeps the result explicit.  (profiles/r03_experiments.md)
-template <bool EARLY_>
+template <bool EARLY>
 HD bool ray_tri(f3 v0, f3 v1, f3 v2, f3 o, f3 d, float tmin, float tmax, float& t, float& b1, float& b2)
 {
-#ifdef HJR_EXP_TRI_EARLY_OFF
-    constexpr bool EARLY = false;
-#else
-    constexpr bool EARLY = EARLY_;
-#endif
     f3 e1 = v1 - v0, e2 = v2 - v0;
     f3 p = crossf(d, e2);
     float det = dotf(e1, p);
@@ -354,9 +349,6 @@ HD bool traverse_fused(const float4* nodes, const float4* tris, const bool a_val
             }
             const uint32_t n_inner = (uint32_t)__popcll(__ballot(!(cur & HJR_LEAF_FLAG)));
             if (n_inner == 0u || n_inner < node_min) break;
-#ifdef HJR_EXP_GREEDY /* experiment: leave the descent as soon as the lanes holding a leaf outnumber (x HJR_EXP_GREEDY / 4) those still descending */
-            if (n_inner * 4u < (uint32_t)__popcll(__ballot((cur & HJR_LEAF_FLAG) && cur != HJR_TRAV_DONE)) * (uint32_t)(HJR_EXP_GREEDY)) break;
-#endif
         }
         // ... then all lanes that hold a leaf test its triangles together
         bool done = (cur == HJR_TRAV_DONE);

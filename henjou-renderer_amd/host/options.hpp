@@ -10,7 +10,7 @@ namespace hjr {
 enum Opt {
     OPT_PIPELINE, OPT_LDS_BVH, OPT_LDS_STACK16, OPT_BVH_WIDTH, OPT_LEAF_MAX, OPT_NODE_MIN, OPT_HOLD_MIN, OPT_HOLD_AGE, OPT_SHORT_STACK,
     OPT_BLOCKS_PER_CU, OPT_TILE_ORDER, OPT_WF_CAP, OPT_WF_REFILL, OPT_WF_PREFETCH_MIN, OPT_WF_TRACE_MIN, OPT_HOST_THREADS, OPT_VERBOSE,
-    OPT_FORCE_REBUILD, OPT_SERIAL_IO, OPT_TOP_NODES, OPT_COUNT
+    OPT_FORCE_REBUILD, OPT_TOP_NODES, OPT_COUNT
 };
 struct OptDesc { const char* key; int lo, hi; };
 // value -1 always means "the library's default"; the ranges are those of explicit values
@@ -35,7 +35,6 @@ inline const OptDesc* opt_table()
         { "host_threads", 1, 256 },  // worker threads of the per-frame host preparation (default min(hardware threads, 16)); process-wide
         { "verbose", 0, 1 },         // 1: BVH format, sizes and host build time per frame on stderr
         { "force_rebuild", 0, 1 },   // 1: rebuild the frame data even when the transforms did not change (benchmarking)
-        { "serial_io", 0, 1 },       // hjr_render_file only (set through "Henjou_HIP": {"serial_io": true}): no overlap of output / next frame's preparation with the render
         { "top_nodes", 0, 1024 },    // memory layouts, BVH4: nodes of the top of the tree every workgroup also stages in LDS (0 none)
     };
     return t;

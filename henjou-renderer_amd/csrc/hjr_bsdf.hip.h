@@ -157,6 +157,18 @@ HD float clearcoat_Lambda(f3 w, float alpha) // :126-129
     float term1 = 1.0f + (alpha * alpha * w.x * w.x + alpha * alpha * w.z * w.z) / (w.y * w.y);
     return 0.5f * (-1.0f + sqrtf(term1));
 }
+// The subsurface, sheen and clearcoat terms enter the result multiplied by 0 when the material's sheen and clearcoat are +0
+// (every material of the glTF path unless an extension sets them; m_subsurface is always 0): each term is then +0 exactly as
+// long as it is finite, which min(|wo.y|, |wi.y|) > 1e-15 guarantees (every denominator below is >= 1e-30, every numerator
+// < 1e5, and the clearcoat factors are positive).  A wave whose lanes are ALL in that case adds the literal +0 instead of
+// computing them (8 correctly rounded divisions and 2 square roots per evaluation); one lane outside it (a grazing direction:
+// the recorded NaN samples of the C2 frame, or a material with sheen / clearcoat) sends the whole wave through the full
+// expression.  Same bits either way.
+HD bool disney_plain(const Disney& d, f3 wo, f3 wi)
+{
+    const bool plain = __float_as_uint(d.sheen) == 0u && __float_as_uint(d.clearcoat) == 0u && fminf(fabsf(wo.y), fabsf(wi.y)) > 1e-15f;
+    return __ballot(!plain) == 0ull;
+}
 HD f3 disney_eval(const KParams& P, const Disney& d, f3 wo, f3 wi) // :179-235
 {
     f3 wm = normalize(wo + wi);
@@ -167,8 +179,7 @@ HD f3 disney_eval(const KParams& P, const Disney& d, f3 wo, f3 wi) // :179-235
     float f_tsi = f_tSchlick(dot_wi_n, F_D90);
     float f_tso = f_tSchlick(dot_wo_n, F_D90);
     f3 f_diffuse = d.basecolor * f_tsi * f_tso * HJ_INV_PI;
-    float deltacos = 1.0f / (dot_wi_n + dot_wo_n) - 0.5f;
-    f3 f_subsurface = d.basecolor * HJ_INV_PI * 1.25f * (f_tsi * f_tso * deltacos + 0.5f);
+    const bool plain = disney_plain(d, wo, wi);
     f3 F0 = lerp3(V1(0.08f), d.basecolor, d.metallic);
     if (d.is_thinfilm) { // :213-217
         float thickness = d.basecolor.x;
@@ -183,6 +194,9 @@ HD f3 disney_eval(const KParams& P, const Disney& d, f3 wo, f3 wi) // :179-235
         f3 ggxF = schlick3(F0, wo, wm);
         f_specular = (ggxF * 0.25f * ggxD * ggxG) / (fabsf(wo.y) * fabsf(wi.y));
     }
+    if (plain) return ((f_diffuse + V1(0.0f)) + V1(0.0f)) * (1.0f - d.metallic) + f_specular + V1(0.0f);
+    float deltacos = 1.0f / (dot_wi_n + dot_wo_n) - 0.5f;
+    f3 f_subsurface = d.basecolor * HJ_INV_PI * 1.25f * (f_tsi * f_tso * deltacos + 0.5f);
     float delta = fmaxf(1.0f - absdot(wi, wm), 0.0f);
     f3 f_sheen = V1(1.0f) * d.sheen * delta * delta * delta * delta * delta;
     // clearcoat(), :142-150
@@ -240,8 +254,13 @@ HD f3 disney_sample(const KParams& P, const Disney& d, f3 wo, f3& wi, float& pdf
     if (lobe != 0) wi = reflect3(-wo, wm);
     pdf_diffuse = d_getPDFDiffuse(wi);
     pdf_specular = d_getPDFSpecular(d.alpha, wm, wo);
-    pdf_clearcoat = d_getPDFClearcoat(wm, wo);
-    pdf = dw * pdf_diffuse + sw * pdf_specular + cw * pdf_clearcoat;
+    // cw is +0: cw * pdf_clearcoat is +0 whenever pdf_clearcoat is finite, i.e. |wm . wo| is not vanishingly small (its numerator is
+    // < 1e5 and not negative); a wave whose lanes all satisfy that adds the literal (same bits), else the wave computes the term.
+    if (__ballot(!(absdot(wm, wo) > 1e-30f)) == 0ull) pdf = (dw * pdf_diffuse + sw * pdf_specular) + 0.0f;
+    else {
+        pdf_clearcoat = d_getPDFClearcoat(wm, wo);
+        pdf = dw * pdf_diffuse + sw * pdf_specular + cw * pdf_clearcoat;
+    }
     if (wi.y < 0.0f) { pdf = 1.0f; return V1(0.0f); }
     return disney_eval(P, d, wo, wi);
 }

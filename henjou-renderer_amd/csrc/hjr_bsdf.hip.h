@@ -91,11 +91,13 @@ HD f3 sky_fetch(const KParams& P, f3 d)
 struct Disney {
     f3 basecolor;
     float alpha, metallic, sheen, clearcoat;
+    float lambda_wo; // d_Lambda(alpha, wo): evaluate (G2), getPDFSpecular (G1) and the evaluate inside sample all need it for the same wo — computed once per shaded hit (disney_lambda_wo)
     bool is_thinfilm;
 };
-HD Disney disney_init(const Surface& s) // :165-177
+HD Disney disney_init(const Surface& s, float lambda_wo) // :165-177
 {
     Disney d;
+    d.lambda_wo = lambda_wo;
     d.basecolor = s.basecolor;
     d.alpha = clampf(s.roughness * s.roughness, 0.01f, 1.0f);
     d.metallic = s.metallic;
@@ -115,8 +117,9 @@ HD float d_Lambda(float a, f3 w) // :58-61
     float delta = 1.0f + (a * a * w.x * w.x + a * a * w.z * w.z) / (w.y * w.y);
     return (-1.0f + sqrtf(delta)) * 0.5f;
 }
-HD float d_G1(float a, f3 w) { return 1.0f / (1.0f + d_Lambda(a, w)); }                             // :50-52
-HD float d_G2(float a, f3 wi, f3 wo) { return 1.0f / (1.0f + d_Lambda(a, wi) + d_Lambda(a, wo)); }   // :54-56
+HD float d_G1(float lambda_w) { return 1.0f / (1.0f + lambda_w); }                                             // :50-52
+HD float d_G2(float a, f3 wi, float lambda_wo) { return 1.0f / (1.0f + d_Lambda(a, wi) + lambda_wo); }            // :54-56
+HD float disney_lambda_wo(const Surface& s, f3 wo) { return d_Lambda(clampf(s.roughness * s.roughness, 0.01f, 1.0f), wo); }
 HD float d_getPDFDiffuse(f3 wi) { return fabsf(wi.y) * HJ_INV_PI; }                                  // :40-42
 // spherical-cap VNDF sampling (arXiv 2306.05044): disneyBRDF.h:64-80 == BSDFs.h:616-632
 HD f3 sample_visible_normal(float alpha, f2 uv, f3 wo)
@@ -133,9 +136,9 @@ HD f3 sample_visible_normal(float alpha, f2 uv, f3 wo)
     f3 h = c + strech_wo;
     return normalize(V(h.x * alpha, h.y, h.z * alpha));
 }
-HD float d_getPDFSpecular(float a, f3 wm, f3 wo) // :88-90
+HD float d_getPDFSpecular(float a, f3 wm, f3 wo, float lambda_wo) // :88-90
 {
-    return 0.25f * ggx_D(a, wm) * d_G1(a, wo) * absdot(wo, wm) / (absdot(wm, wo) * fabsf(wo.y));
+    return 0.25f * ggx_D(a, wm) * d_G1(lambda_wo) * absdot(wo, wm) / (absdot(wm, wo) * fabsf(wo.y));
 }
 HD float clearcoat_D(f3 wm, float alpha) // :131-139
 {
@@ -190,7 +193,7 @@ HD f3 disney_eval(const KParams& P, const Disney& d, f3 wo, f3 wi) // :179-235
     f3 f_specular;
     {
         float ggxD = ggx_D(d.alpha, wm);
-        float ggxG = d_G2(d.alpha, wi, wo);
+        float ggxG = d_G2(d.alpha, wi, d.lambda_wo);
         f3 ggxF = schlick3(F0, wo, wm);
         f_specular = (ggxF * 0.25f * ggxD * ggxG) / (fabsf(wo.y) * fabsf(wi.y));
     }
@@ -253,7 +256,7 @@ HD f3 disney_sample(const KParams& P, const Disney& d, f3 wo, f3& wi, float& pdf
     if (lobe != 2) wm = normalize(v);
     if (lobe != 0) wi = reflect3(-wo, wm);
     pdf_diffuse = d_getPDFDiffuse(wi);
-    pdf_specular = d_getPDFSpecular(d.alpha, wm, wo);
+    pdf_specular = d_getPDFSpecular(d.alpha, wm, wo, d.lambda_wo);
     // cw is +0: cw * pdf_clearcoat is +0 whenever pdf_clearcoat is finite, i.e. |wm . wo| is not vanishingly small (its numerator is
     // < 1e5 and not negative); a wave whose lanes all satisfy that adds the literal (same bits), else the wave computes the term.
     if (__ballot(!(absdot(wm, wo) > 1e-30f)) == 0ull) pdf = (dw * pdf_diffuse + sw * pdf_specular) + 0.0f;
@@ -271,7 +274,7 @@ HD float disney_pdf(const Disney& d, f3 wo, f3 wi) // :309-326
     float sumWeight = diffuseWeight + specularWeight + clearcoatWeight;
     float dw = diffuseWeight / sumWeight, sw = specularWeight / sumWeight;
     f3 wm = normalize(wo + wi);
-    return dw * d_getPDFDiffuse(wi) + sw * d_getPDFSpecular(d.alpha, wm, wo);
+    return dw * d_getPDFDiffuse(wi) + sw * d_getPDFSpecular(d.alpha, wm, wo, d.lambda_wo);
 }
 
 // ------------------------------------------------------------------ MetaMaterialGlass (kernel/BSDFs.h:404-479): negative refractive index
@@ -355,24 +358,25 @@ HD f3 msggx_sampleBSDF(f3 F0, float alpha, f3 wo_in, f3& wi_out, CMJState& st, f
 }
 
 // ------------------------------------------------------------------ BSDF dispatch (kernel/BSDFs.h:979-1038)
-HD f3 bsdf_eval(const KParams& P, const Surface& s, f3 wo, f3 wi)
+// lambda_wo = disney_lambda_wo(s, wo), computed once by the caller for all the calls of one shaded hit
+HD f3 bsdf_eval(const KParams& P, const Surface& s, f3 wo, f3 wi, float lambda_wo)
 {
     if (s.is_specular) return V1(0.0f);
-    Disney d = disney_init(s);
+    Disney d = disney_init(s, lambda_wo);
     return disney_eval(P, d, wo, wi);
 }
-HD f3 bsdf_sample(const KParams& P, const Surface& s, f3 wo, f3& wi, float& pdf, CMJState& st)
+HD f3 bsdf_sample(const KParams& P, const Surface& s, f3 wo, f3& wi, float& pdf, CMJState& st, float lambda_wo)
 {
     if (s.is_specular) return metaglass_sample(s.ior, wo, wi, pdf, st);
     if (!(s.metallic > 0.5f)) {
-        Disney d = disney_init(s);
+        Disney d = disney_init(s, lambda_wo);
         return disney_sample(P, d, wo, wi, pdf, st);
     }
     return msggx_sampleBSDF(s.basecolor, clampf(s.roughness * s.roughness, 0.0001f, 1.0f), wo, wi, st, pdf);
 }
-HD float bsdf_pdf(const Surface& s, f3 wo, f3 wi)
+HD float bsdf_pdf(const Surface& s, f3 wo, f3 wi, float lambda_wo)
 {
     if (s.is_specular) return 0.0f;
-    Disney d = disney_init(s);
+    Disney d = disney_init(s, lambda_wo);
     return disney_pdf(d, wo, wi);
 }

@@ -146,18 +146,26 @@ HD f3 light_sample(const KParams& P, const float4* lights, CMJState& st, float& 
 
 struct PathState {
     f3 ro, rd, thr, L;
-    uint32_t rng_depth; // CMJState.depth; the other CMJState fields are functions of (frame, spp, s, seed, pixel): rebuilt on use
+    uint32_t rng_depth; // CMJState.depth
+    uint32_t rng_head;  // CMJState.head: a function of (frame, spp, s, seed, pixel), computed when the sample starts.  The megakernel carries
+                        // it in a register (two hash prefixes less per round); the wavefront kernel's context record has no room for it and
+                        // rebuilds it when it loads a context (path_head)
     int depth;
 };
 
 // CMJState of the path that is running sample s of pixel (px, py) (build-defined seeding)
 HD CMJState path_rng(const KParams& P, uint32_t px, uint32_t py, uint32_t s, uint32_t depth)
 {
+    return cmj_state((unsigned long long)P.frame * (unsigned long long)P.spp + (unsigned long long)s, P.seed, px + py * P.width, depth);
+}
+HD uint32_t path_head(const KParams& P, uint32_t px, uint32_t py, uint32_t s) { return path_rng(P, px, py, s, 0u).head; }
+// the same state from a stored head: index = (frame * spp + s) % 16 needs the low bits of the sum only
+HD CMJState path_rng_from_head(const KParams& P, uint32_t head, uint32_t s, uint32_t depth)
+{
     CMJState st;
-    st.n_spp = (unsigned long long)P.frame * (unsigned long long)P.spp + (unsigned long long)s;
-    st.scramble = P.seed;
+    st.head = head;
+    st.index = (P.frame * P.spp + s) & 15u;
     st.depth = depth;
-    st.image_idx = px + py * P.width;
     return st;
 }
 
@@ -166,6 +174,7 @@ HD CMJState path_rng(const KParams& P, uint32_t px, uint32_t py, uint32_t s, uin
 HD void start_path(const KParams& P, PathState& ps, uint32_t px, uint32_t py, uint32_t s)
 {
     CMJState st = path_rng(P, px, py, s, 0u);
+    ps.rng_head = st.head;
     f2 j = cmj_2d(st);
     ps.rng_depth = st.depth;
     float W = (float)P.width, H = (float)P.height;
@@ -223,7 +232,7 @@ HD void ctx_reset(LaneCtx& c)
     c.sumL = c.sumA = c.sumN = c.sh_d = c.sh_contrib = c.mis_contrib = V1(0.0f);
     c.sh_tmax = 0.0f;
     c.ps.ro = c.ps.rd = c.ps.thr = c.ps.L = V1(0.0f);
-    c.ps.depth = 0; c.ps.rng_depth = 0;
+    c.ps.depth = 0; c.ps.rng_depth = 0; c.ps.rng_head = 0;
 }
 #define HJR_PX(c) ((c).item & 0x1fffu)
 #define HJR_PY(c) (((c).item >> 13) & 0x1fffu)
@@ -363,7 +372,7 @@ HD void bounce_pre_trace(const KParams& P, LaneCtx& c, WaveRange& wr, const bool
     if (active) {
         if (c.has_item && c.path_live) { // continuing path
             const float russian_p = fmaxf(c.ps.thr.x, fmaxf(c.ps.thr.y, c.ps.thr.z));
-            CMJState rr = path_rng(P, HJR_PX(c), HJR_PY(c), c.s, c.ps.rng_depth);
+            CMJState rr = path_rng_from_head(P, c.ps.rng_head, c.s, c.ps.rng_depth);
             const float xi_rr = cmj_1d(rr);
             c.ps.rng_depth = rr.depth;
             if (russian_p < xi_rr) {
@@ -520,12 +529,13 @@ HD void bounce_post_trace(const KParams& P, const float4* nodes, const float4* t
         if (!ONEWRITE && c.write_pending) write_out<AOVS>(P, c);
         return;
     }
-    CMJState st = path_rng(P, HJR_PX(c), HJR_PY(c), c.s, ps.rng_depth);
+    CMJState st = path_rng_from_head(P, ps.rng_head, c.s, ps.rng_depth);
     const Surface& sf = prd.surf;
     f3 t, b;
     const f3 n = prd.normal;
     orthonormal_basis(n, t, b);
     const f3 local_wo = world_to_local(-ps.rd, t, n, b);
+    const float lambda_wo = disney_lambda_wo(sf, local_wo); // shared by every Disney evaluate / pdf of this hit
 
     if (INTEGRATOR != HJR_INTEGRATOR_PT_ && P.n_lights >= 1u) { // light_prim_count < 1: no contribution (UB in the reference)
         float light_pdf;
@@ -548,12 +558,12 @@ HD void bounce_post_trace(const KParams& P, const float4* nodes, const float4* t
         const float cosine1 = absdot(n, sd);
         const float cosine2 = absdot(light_normal, -sd);
         const f3 local_wi = world_to_local(sd, t, n, b);
-        const f3 bsdf = bsdf_eval(P, sf, local_wo, local_wi);
+        const f3 bsdf = bsdf_eval(P, sf, local_wo, local_wi, lambda_wo);
         const float G = cosine2 / (light_distance * light_distance);
         if (INTEGRATOR == HJR_INTEGRATOR_NEE_) {
             c.sh_contrib = (ps.thr * ((bsdf * G * cosine1) / light_pdf)) * light_color; // rt.h:258
         } else {
-            const float pt_pdf = bsdf_pdf(sf, local_wo, local_wi) * G;
+            const float pt_pdf = bsdf_pdf(sf, local_wo, local_wi, lambda_wo) * G;
             const float mis_weight = light_pdf / (light_pdf + pt_pdf);
             c.sh_contrib = ((ps.thr * ((bsdf * G * cosine1) / light_pdf)) * mis_weight) * light_color; // rt.h:378
         }
@@ -570,7 +580,7 @@ HD void bounce_post_trace(const KParams& P, const float4* nodes, const float4* t
         // float additions is the reference's.  Without a pending NEE term (exactly-zero contribution, no lights) it is added at once.
         float pt_pdf = 1.0f; // uninitialised in the reference when msGGX returns early; defined as 1
         f3 local_wi = V(0.0f, 1.0f, 0.0f);
-        const f3 brdf = bsdf_sample(P, sf, local_wo, local_wi, pt_pdf, st);
+        const f3 brdf = bsdf_sample(P, sf, local_wo, local_wi, pt_pdf, st, lambda_wo);
         const f3 wi = local_to_world(local_wi, t, n, b);
         const float cosine1 = absdot(wi, n);
         HitInfo lh;
@@ -616,7 +626,7 @@ HD void bounce_post_trace(const KParams& P, const float4* nodes, const float4* t
     float pdf = 1.0f;
     f3 local_wi = V(0.0f, 1.0f, 0.0f);
     if (INTEGRATOR != HJR_INTEGRATOR_PT_) (void)cmj_2d(st); // drawn and discarded by the reference (rt.h:266, 426)
-    const f3 bsdf = bsdf_sample(P, sf, local_wo, local_wi, pdf, st);
+    const f3 bsdf = bsdf_sample(P, sf, local_wo, local_wi, pdf, st, lambda_wo);
     const f3 wi = local_to_world(local_wi, t, n, b);
     ps.thr = ps.thr * ((bsdf * fabsf(dot(wi, n))) / pdf); // rt.h:274
     ps.ro = prd.position;

@@ -1,42 +1,20 @@
 // CMJ sample streams (kernel/cmj.h) and the small sampling / shading-frame helpers of kernel/math.h, restated for gfx950.
 #pragma once
 #include "hjr_params.hip.h"
+#include "hjr_cmj.h"
 
 // ------------------------------------------------------------------ kernel/cmj.h
-struct CMJState { unsigned long long n_spp; uint32_t scramble, depth, image_idx; }; // cmj.h:53-58
-
-HD uint32_t xxhash32_u4(uint32_t px, uint32_t py, uint32_t pz, uint32_t pw) // cmj.h:38-51
+// CMJState (cmj.h:53-58) holds {n_spp, scramble (seed), depth, image_idx}; every draw hashes (n_spp / 16, image_idx, depth, seed) and
+// uses n_spp % 16 as the index in its 4 x 4 pattern (cmj.h:119-128).  Only the depth changes between the draws of one path sample, so the
+// state carried here is the hash after the three constant words (`head`), the index, and the depth.
+struct CMJState { uint32_t head, index, depth; };
+HD CMJState cmj_state(unsigned long long n_spp, uint32_t seed, uint32_t image_idx, uint32_t depth)
 {
-    const uint32_t P2 = 2246822519U, P3 = 3266489917U, P4 = 668265263U, P5 = 374761393U;
-    uint32_t h = pw + P5 + px * P3;
-    h = P4 * ((h << 17) | (h >> 15));
-    h += py * P3;
-    h = P4 * ((h << 17) | (h >> 15));
-    h += pz * P3;
-    h = P4 * ((h << 17) | (h >> 15));
-    h = P2 * (h ^ (h >> 15));
-    h = P3 * (h ^ (h >> 13));
-    return h ^ (h >> 16);
-}
-HD uint32_t cmj_permute(uint32_t i, uint32_t l, uint32_t p) // cmj.h:60-91
-{
-    uint32_t w = l - 1;
-    w |= w >> 1; w |= w >> 2; w |= w >> 4; w |= w >> 8; w |= w >> 16;
-    do {
-        i ^= p; i *= 0xe170893d;
-        i ^= p >> 16;
-        i ^= (i & w) >> 4;
-        i ^= p >> 8; i *= 0x0929eb3f;
-        i ^= p >> 23;
-        i ^= (i & w) >> 1; i *= 1 | p >> 27;
-        i *= 0x6935fa69;
-        i ^= (i & w) >> 11; i *= 0x74dcb303;
-        i ^= (i & w) >> 2; i *= 0x9e501cc3;
-        i ^= (i & w) >> 2; i *= 0xc860a3df;
-        i &= w;
-        i ^= i >> 5;
-    } while (i >= l);
-    return (i + p) % l;
+    CMJState st;
+    st.head = hjr_xxhash_head((uint32_t)(n_spp / 16), image_idx, seed);
+    st.index = (uint32_t)(n_spp % 16);
+    st.depth = depth;
+    return st;
 }
 HD float cmj_randfloat(uint32_t i, uint32_t p) // cmj.h:93-106
 {
@@ -47,11 +25,11 @@ HD float cmj_randfloat(uint32_t i, uint32_t p) // cmj.h:93-106
     i ^= i >> 17; i *= 1 | p >> 18;
     return i * (1.0f / 4294967808.0f);
 }
-HD f2 cmj(uint32_t index, uint32_t scramble) // cmj.h:108-117
+HD f2 cmj(uint32_t index, uint32_t scramble) // cmj.h:108-117; permute(i, 16 / 4, p): hjr_cmj.h
 {
-    index = cmj_permute(index, 16, scramble * 0x51633e2d);
-    uint32_t sx = cmj_permute(index % 4, 4, scramble * 0xa511e9b3);
-    uint32_t sy = cmj_permute(index / 4, 4, scramble * 0x63d83595);
+    index = hjr_cmj_permute16(index, scramble * 0x51633e2d);
+    uint32_t sx = hjr_cmj_permute4(index % 4, scramble * 0xa511e9b3);
+    uint32_t sy = hjr_cmj_permute4(index / 4, scramble * 0x63d83595);
     float jx = cmj_randfloat(index, scramble * 0xa399d265);
     float jy = cmj_randfloat(index, scramble * 0x711ad6a5);
     f2 r;
@@ -61,9 +39,8 @@ HD f2 cmj(uint32_t index, uint32_t scramble) // cmj.h:108-117
 }
 HD f2 cmj_2d(CMJState& st) // cmj.h:119-128
 {
-    const uint32_t index = (uint32_t)(st.n_spp % 16);
-    const uint32_t scramble = xxhash32_u4((uint32_t)(st.n_spp / 16), st.image_idx, st.depth, st.scramble);
-    f2 r = cmj(index, scramble);
+    const uint32_t scramble = hjr_xxhash_tail(st.head, st.depth);
+    f2 r = cmj(st.index, scramble);
     st.depth++;
     return r;
 }

@@ -405,6 +405,7 @@ HD void wf_shade_stage(const KParams& P, WfShared* Q, wf_ring_ptr rings, int q, 
         id = wf_take(rings, q, start + lane, cap);
         float4 hr;
         wf_load_ctx(ctx, id, c, tracing, hr);
+        c.ps.rng_head = path_head(P, HJR_PX(c), HJR_PY(c), c.s); // not in the record: rebuilt once per pass, used by both halves of the bounce
         if (AOVS) c.aov = P.wf_aov + ((size_t)blockIdx.x * cap + id) * HJR_WF_AOV_F4; // the item's albedo / normal sums live here, not in the record
 #ifdef HJR_WF_TIMING
         __builtin_amdgcn_s_waitcnt(0x0070); // vmcnt(0): the loads have landed

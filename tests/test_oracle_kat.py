@@ -66,6 +66,49 @@ def test_cmj_permute_exact():
         assert L.hjo_cmj_permute(*c["in"]) == c["out"]
 
 
+@pytest.fixture(scope="module")
+def narrow(tmp_path_factory):
+    """henjou-renderer_amd/csrc/hjr_cmj.h (the product's mod-2^k permutes and split xxhash32) compiled for the host."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = str(tmp_path_factory.mktemp("cmj") / "cmj_narrow.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", os.path.join(root, "tests", "native", "cmj_narrow_test.cpp"), "-o", so])
+    N = C.CDLL(so)
+    for f in ("sweep", "sweep_bijective"):
+        getattr(N, f).restype = C.c_uint64
+        getattr(N, f).argtypes = [C.c_uint64, C.c_uint64]
+    for f, n in (("narrow_permute16", 2), ("narrow_permute4", 2), ("split_xxhash", 4)):
+        getattr(N, f).restype = C.c_uint32
+        getattr(N, f).argtypes = [C.c_uint32] * n
+    return N
+
+
+def test_product_cmj_integer_functions_equal_the_32_bit_loop(narrow):
+    """Every i < l for 4 M random and 4096 structured p (l = 16 and l = 4), and the split hash, against the spelled-out originals."""
+    assert narrow.sweep(4_000_000, 20260315) == 0
+    assert narrow.sweep_bijective(500_000, 7) == 0
+
+
+def test_product_cmj_integer_functions_equal_the_oracle_and_the_kat(narrow):
+    for c in KAT["cmj_permute"]:
+        i, l, p = c["in"]
+        if l == 16 and i < 16:
+            assert narrow.narrow_permute16(i, p) == c["out"]
+        if l == 4 and i < 4:
+            assert narrow.narrow_permute4(i, p) == c["out"]
+    for c in KAT["xxhash32_u4"]:
+        assert narrow.split_xxhash(*c["in"]) == c["out"]
+    rng = np.random.default_rng(5)
+    for p in rng.integers(0, 2**32, 3000, dtype=np.uint64):
+        p = int(p)
+        for i in range(16):
+            assert narrow.narrow_permute16(i, p) == L.hjo_cmj_permute(i, 16, p)
+        for i in range(4):
+            assert narrow.narrow_permute4(i, p) == L.hjo_cmj_permute(i, 4, p)
+    for a, b, c_, d in rng.integers(0, 2**32, (3000, 4), dtype=np.uint64):
+        assert narrow.split_xxhash(int(a), int(b), int(c_), int(d)) == L.hjo_xxhash32_u4(int(a), int(b), int(c_), int(d))
+
+
 def test_cmj_randfloat_and_cmj_bitexact():
     for c in KAT["cmj_randfloat"]:
         assert f32eq(L.hjo_cmj_randfloat(*c["in"]), c["out"])

@@ -157,8 +157,9 @@ extern "C" int hjr_prepare_transforms(hjr_ctx* c, const float* m, const float* i
     bo.prefer_stack16 = c->opt.get(hjr::OPT_LDS_STACK16, 0) != 0;
     bo.bvh_width = c->opt.get(hjr::OPT_BVH_WIDTH, -1);
     bo.leaf_max = c->opt.get(hjr::OPT_LEAF_MAX, -1);
+    bo.refine = c->opt.get(hjr::OPT_BVH_REFINE, -1);
     bo.timing = c->opt.get(hjr::OPT_VERBOSE, 0) != 0;
-    const uint32_t build_tag = (bo.allow_lds ? 1u : 0u) | (bo.prefer_stack16 ? 2u : 0u) | ((uint32_t)(bo.bvh_width + 1) << 2) | ((uint32_t)(bo.leaf_max + 1) << 6);
+    const uint32_t build_tag = (bo.allow_lds ? 1u : 0u) | (bo.prefer_stack16 ? 2u : 0u) | ((uint32_t)(bo.bvh_width + 1) << 2) | ((uint32_t)(bo.leaf_max + 1) << 6) | ((uint32_t)(bo.refine + 1) << 10);
     c->pending_valid = false;
     c->pending_same = false;
     // unchanged instance transforms (static geometry, e.g. a camera-only animation): the world-space arrays and the BVH of the

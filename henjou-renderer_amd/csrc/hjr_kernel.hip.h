@@ -120,7 +120,7 @@ HD void ray_trace(const KParams& P, const float4* nodes, const float4* tris, con
 }
 
 // light_sample (kernel/light_sample.h:9-75) on the per-frame light table
-HD f3 light_sample(const KParams& P, const float4* lights, CMJState& st, float& pdf, f3& normal, f3& emission)
+HD f3 light_sample(const KParams& P, const float4* lights, CMJState& st, float& pdf, float& inv_pdf, f3& normal, f3& emission)
 {
     float p = cmj_1d(st);
     int index = (int)(p * P.n_lights);
@@ -134,6 +134,7 @@ HD f3 light_sample(const KParams& P, const float4* lights, CMJState& st, float& 
     const f3 light_position = V(l0.x, l0.y, l0.z) * f1 + V(l1.x, l1.y, l1.z) * f2_ + V(l2.x, l2.y, l2.z) * f3_;
     normal = normalize(V(l3.x, l3.y, l3.z) * f1 + V(l4.x, l4.y, l4.z) * f2_ + V(l5.x, l5.y, l5.z) * f3_);
     pdf = l0.w;
+    inv_pdf = l5.w; // 1.0f / pdf, divided once per frame by the host
     emission = V(l1.w, l2.w, l3.w);
     return light_position;
 }
@@ -538,9 +539,9 @@ HD void bounce_post_trace(const KParams& P, const float4* nodes, const float4* t
     const float lambda_wo = disney_lambda_wo(sf, local_wo); // shared by every Disney evaluate / pdf of this hit
 
     if (INTEGRATOR != HJR_INTEGRATOR_PT_ && P.n_lights >= 1u) { // light_prim_count < 1: no contribution (UB in the reference)
-        float light_pdf;
+        float light_pdf, inv_light_pdf;
         f3 light_color, light_normal;
-        const f3 light_position = light_sample(P, lights, st, light_pdf, light_normal, light_color);
+        const f3 light_position = light_sample(P, lights, st, light_pdf, inv_light_pdf, light_normal, light_color);
         if (STATS) lc[8] += 1;
         const f3 so = prd.position;
         f3 sd;
@@ -561,11 +562,11 @@ HD void bounce_post_trace(const KParams& P, const float4* nodes, const float4* t
         const f3 bsdf = bsdf_eval(P, sf, local_wo, local_wi, lambda_wo);
         const float G = cosine2 / (light_distance * light_distance);
         if (INTEGRATOR == HJR_INTEGRATOR_NEE_) {
-            c.sh_contrib = (ps.thr * ((bsdf * G * cosine1) / light_pdf)) * light_color; // rt.h:258
+            c.sh_contrib = (ps.thr * ((bsdf * G * cosine1) * inv_light_pdf)) * light_color; // rt.h:258: float3 / light_pdf
         } else {
             const float pt_pdf = bsdf_pdf(sf, local_wo, local_wi, lambda_wo) * G;
             const float mis_weight = light_pdf / (light_pdf + pt_pdf);
-            c.sh_contrib = ((ps.thr * ((bsdf * G * cosine1) / light_pdf)) * mis_weight) * light_color; // rt.h:378
+            c.sh_contrib = ((ps.thr * ((bsdf * G * cosine1) * inv_light_pdf)) * mis_weight) * light_color; // rt.h:378
         }
         c.sh_d = sd; c.sh_tmax = light_distance - 0.001f; // origin = prd.position = ps.ro below
         // an exactly-zero contribution (every hit on the glass lobe, whose evaluateBSDF is 0) cannot change L whatever

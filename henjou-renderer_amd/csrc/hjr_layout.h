@@ -59,7 +59,7 @@ HJR_LAYOUT_FN void hjr_tile_xy(uint32_t t, uint32_t tiles_x, uint32_t* tx, uint3
 /* Material, 80 B = hjr_material verbatim (include/henjou_hip.h); m4 = (metallic_roughness_tex, normal_tex, emission_tex, -) */
 #define HJR_MAT_F4 5
 /* Light triangle, 96 B = 6 x float4 (light_sample.h:43-72 hoisted to once per frame):
- *   l0 = (v0.xyz pdf)  l1 = (v1.xyz em.x)  l2 = (v2.xyz em.y)  l3 = (n0.xyz em.z)  l4 = (n1.xyz 0)  l5 = (n2.xyz 0)
+ *   l0 = (v0.xyz pdf)  l1 = (v1.xyz em.x)  l2 = (v2.xyz em.y)  l3 = (n0.xyz em.z)  l4 = (n1.xyz prim)  l5 = (n2.xyz 1.0f / pdf)
  *   v*: transform_position(transforms[inst]); n*: transform_normal(inv_transforms[inst]) (NOT normalised);
  *   pdf = float(1.0 / area) * (1.0f / light_prim_count) */
 #define HJR_LIGHT_F4 6

@@ -10,7 +10,7 @@ namespace hjr {
 enum Opt {
     OPT_PIPELINE, OPT_LDS_BVH, OPT_LDS_STACK16, OPT_BVH_WIDTH, OPT_LEAF_MAX, OPT_NODE_MIN, OPT_HOLD_MIN, OPT_HOLD_AGE, OPT_SHORT_STACK,
     OPT_BLOCKS_PER_CU, OPT_TILE_ORDER, OPT_WF_CAP, OPT_WF_REFILL, OPT_WF_PREFETCH_MIN, OPT_WF_TRACE_MIN, OPT_HOST_THREADS, OPT_VERBOSE,
-    OPT_FORCE_REBUILD, OPT_TOP_NODES, OPT_COUNT
+    OPT_FORCE_REBUILD, OPT_TOP_NODES, OPT_BVH_REFINE, OPT_COUNT
 };
 struct OptDesc { const char* key; int lo, hi; };
 // value -1 always means "the library's default"; the ranges are those of explicit values
@@ -36,6 +36,7 @@ inline const OptDesc* opt_table()
         { "verbose", 0, 1 },         // 1: BVH format, sizes and host build time per frame on stderr
         { "force_rebuild", 0, 1 },   // 1: rebuild the frame data even when the transforms did not change (benchmarking)
         { "top_nodes", 0, 1024 },    // memory layouts, BVH4: nodes of the top of the tree every workgroup also stages in LDS (0 none)
+        { "bvh_refine", 0, 16 },     // insertion-based refinement passes over the built BVH2 (default 0 up to 65536 triangles, 1 above)  [next hjr_set_transforms]
     };
     return t;
 }
@@ -55,7 +56,7 @@ struct Options {
 // what host/frame.cpp needs of them
 struct BuildOptions {
     bool allow_lds = true, prefer_stack16 = false, timing = false;
-    int bvh_width = -1, leaf_max = -1;
+    int bvh_width = -1, leaf_max = -1, refine = -1;
 };
 void set_host_threads(int n); // host/frame.cpp; n <= 0 restores the default
 

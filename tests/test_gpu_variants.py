@@ -121,6 +121,17 @@ def test_memory_layouts_on_a_deep_scene(tmp_path):
                  expect_overflow=True)
 
 
+@pytest.mark.parametrize("passes", [0, 1, 8])
+def test_bvh_refinement_changes_the_tree_not_the_frame(cornell, tmp_path, passes):
+    """Option "bvh_refine" (insertion-based refinement of the built BVH2, host/frame.cpp::Refine): none / one / eight passes give a
+    different tree (depth) and the same bits, in the LDS layout of the bundled scene and the memory layouts of a 60 k-triangle one."""
+    st = check_layout(cornell, "cornell", {"HJR_BVH_REFINE": passes}, expect_mode=1, integrators=(hjr.INTEGRATOR_NEE, hjr.INTEGRATOR_MIS))
+    assert st["bvh_depth"] == (12 if passes == 0 else st["bvh_depth"]) and (passes == 0 or st["bvh_depth"] != 12), st
+    s = StressScene(tmp_path, spheres=8, segments=88)
+    check_layout(s, "ss8x88", {"HJR_BVH_REFINE": passes}, expect_mode=0, w=64, h=36, spp=2, integrators=(hjr.INTEGRATOR_NEE,))
+    check_layout(s, "ss8x88", {"HJR_BVH_REFINE": passes, "HJR_BVH_WIDTH": 2}, expect_mode=3, w=64, h=36, spp=2, integrators=(hjr.INTEGRATOR_NEE,))
+
+
 # ---- the workgroup-local wavefront kernel family (hjr_wavefront.hip.h): same layouts, same bar
 WF = "wf"
 

@@ -1,6 +1,6 @@
 // Host-side timing of hjr::build_frame (flatten + BVH build + emit) for a render_option.json scene.
 //   g++ -O3 -std=c++17 -I. tools/frame_build_bench.cpp henjou-renderer_amd/host/{loaders,frame,image_io,jpeg}.cpp -lz -pthread -o /tmp/fbb
-//   /tmp/fbb <dir containing render_option + Model/> <render_option.json> [repeats]
+//   /tmp/fbb <dir containing render_option + Model/> <render_option.json> [repeats [threads [verbose [refine passes]]]]
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -20,6 +20,8 @@ int main(int argc, char** argv)
     if (argc > 4) hjr::set_host_threads(atoi(argv[4])); // worker threads (default min(hardware threads, 16))
     hjr::BuildOptions bo;
     bo.timing = argc > 5 && atoi(argv[5]) != 0;          // stage times on stderr
+    if (argc > 6) bo.refine = atoi(argv[6]);             // option "bvh_refine" (passes; -1 default)
+    if (argc > 7) bo.bvh_width = atoi(argv[7]);          // option "bvh_width"
     std::string err;
     hjr_render_option opt;
     HJR_INIT(opt);

@@ -314,8 +314,11 @@ def main():
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
-            ms.append(r.device.stats()["last_kernel_ms"])  # HIP events recorded on the launch stream around the kernel(s)
+            if world == 1:
+                ms.append(r.device.stats()["last_kernel_ms"])  # HIP events recorded on the launch stream around the kernel(s); waits for the step
         fence()
+        if world > 1:  # sharded steps are short (1 / N of a frame): no host wait inside the timed region, the last step's kernel time only
+            ms.append(r.device.stats()["last_kernel_ms"])
         el = time.perf_counter() - t0
         if world > 1:
             t = torch.tensor([el], dtype=torch.float64, device="cuda")

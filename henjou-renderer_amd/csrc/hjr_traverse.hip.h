@@ -178,10 +178,15 @@ HD uint32_t node_step(const float4* nodes, uint32_t& cur, const BoxRay<WIDTH, ST
     const v2f nz = node_ld<v2f>(anz, 0), fz = node_ld<v2f>(node_far(anz), 0);
     const v2u cc = node_ld<v2u>(anx, 48); // the child refs are stored twice (bytes 48 and 56): one immediate offset from the near-x address
     const f3 inv = R.inv, oi = R.oi;
+    // min(t, tfar) spelled as the instruction: fminf() puts a quieting copy of tfar (v_max_f32 t, t) in front of it in every step of this loop,
+    // because the compiler cannot see that hit.t is never a signalling NaN; the operands here never are NaNs at all (finite planes, clamped directions)
+    float fz0 = fmaf(fz.x, inv.z, oi.z), fz1 = fmaf(fz.y, inv.z, oi.z);
+    asm("v_min_f32 %0, %1, %2" : "=v"(fz0) : "v"(fz0), "v"(tfar));
+    asm("v_min_f32 %0, %1, %2" : "=v"(fz1) : "v"(fz1), "v"(tfar));
     const float lo0 = fmaxf(fmaxf(fmaf(nx.x, inv.x, oi.x), fmaf(ny.x, inv.y, oi.y)), fmaxf(fmaf(nz.x, inv.z, oi.z), tmin));
-    const float hi0 = fminf(fminf(fmaf(fx.x, inv.x, oi.x), fmaf(fy.x, inv.y, oi.y)), fminf(fmaf(fz.x, inv.z, oi.z), tfar));
+    const float hi0 = fminf(fminf(fmaf(fx.x, inv.x, oi.x), fmaf(fy.x, inv.y, oi.y)), fz0);
     const float lo1 = fmaxf(fmaxf(fmaf(nx.y, inv.x, oi.x), fmaf(ny.y, inv.y, oi.y)), fmaxf(fmaf(nz.y, inv.z, oi.z), tmin));
-    const float hi1 = fminf(fminf(fmaf(fx.y, inv.x, oi.x), fmaf(fy.y, inv.y, oi.y)), fminf(fmaf(fz.y, inv.z, oi.z), tfar));
+    const float hi1 = fminf(fminf(fmaf(fx.y, inv.x, oi.x), fmaf(fy.y, inv.y, oi.y)), fz1);
     const bool h0 = lo0 <= hi0, h1 = lo1 <= hi1; // conservative through the 2^-15 box padding (>= 16x the rounding error of t)
     const uint32_t c0 = cc.x, c1 = cc.y;
     // (the push stays a branch here: writing the farther child unconditionally and advancing the top by 0 / 1, as the BVH4 step below does,

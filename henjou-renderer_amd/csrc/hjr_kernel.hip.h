@@ -252,7 +252,14 @@ struct SharedRange {
     uint32_t lock;            // 1 while a wave is fetching the next range
     uint32_t exhausted;       // the global queue has run dry (set under the lock)
 };
-struct WaveRange { uint32_t next, end; bool exhausted; SharedRange* shared; };
+struct WaveRange {
+    uint32_t next, end; bool exhausted; SharedRange* shared;
+    // megakernel: a private range is 64 aligned items = ONE (tile, sample chunk).  Its decode — two integer divisions, the tile-order
+    // look-up, the tile's diagonal id turned back into (x, y) — is done once when the range is fetched, wave-uniform, not by every lane
+    // at every refill (a wave refills some lane in nearly every round: ~120 instructions per round): the item word of the range's
+    // pixel (0, 0)
+    uint32_t base_item;
+};
 #ifndef HJR_WF_ITEM_FETCH
 #define HJR_WF_ITEM_FETCH 256u /* items per refill of a workgroup's shared range */
 #endif
@@ -359,6 +366,16 @@ template <bool AOVS> HD void write_out(const KParams& P, LaneCtx& c)
     c.write_pending = false;
 }
 
+// decode of the 64 aligned items [base, base + 64) of the megakernel's queue: item q = ((owned tile * n_chunks) + chunk) * 64 + pixel-in-tile
+HD uint32_t decode_range(uint32_t base, uint32_t n_chunks, uint32_t tiles_x, uint32_t world, uint32_t rank, const uint32_t* tile_order)
+{
+    const uint32_t tc = base >> 6;
+    const uint32_t owned = tc / n_chunks, chunk = tc - owned * n_chunks;
+    const uint32_t tile = tile_order ? tile_order[owned] : owned * world + rank;
+    uint32_t tx, ty;
+    hjr_tile_xy(tile, tiles_x, &tx, &ty);
+    return (tx * HJR_TILE) | ((ty * HJR_TILE) << 13) | (chunk << 26);
+}
 // ---- first half of a bounce.  ALL 64 lanes of the wave must call it together (ballots and shuffles inside); `active` is
 // false for lanes that sit this round out (megakernel: lanes whose traversal is carried over; wavefront: lanes without a
 // context).  On return `tracing` says whether the lane has a closest-hit ray to trace (origin: camera if c.fresh, else c.ps.ro;
@@ -408,6 +425,7 @@ HD void bounce_pre_trace(const KParams& P, LaneCtx& c, WaveRange& wr, const bool
             const uint32_t* const tile_order = HJR_COLD(tile_order);
             uint32_t* const tile_cost = HJR_COLD(tile_cost);
             uint32_t q;
+            uint32_t r_item = 0u; // item word of pixel (0, 0) of the range this lane's item comes from
             bool again = false; // shared range only: unserved lanes ask again in their next pass instead of retiring
             if (wr.shared) { // wavefront kernel: the workgroup's shared range
                 uint32_t a0 = 0, n0 = 0, a1 = 0, n1 = 0, dry = 1u;
@@ -419,6 +437,7 @@ HD void bounce_pre_trace(const KParams& P, LaneCtx& c, WaveRange& wr, const bool
             } else {
             q = wr.next + prefix;                   // wave-uniform wr.next / wr.end
             const uint32_t have = wr.end - wr.next; // items left in the private range
+            r_item = wr.base_item;
             if (n > have) {                         // not enough: lanes beyond `have` come from a fresh range
                 // once a wave has seen the queue run dry it never touches the head again (wave-uniform flag): the 32-bit head
                 // overshoots n_owned_items by at most 64 per wave of the grid and cannot wrap (hjr_device.hip keeps that margin)
@@ -432,42 +451,40 @@ HD void bounce_pre_trace(const KParams& P, LaneCtx& c, WaveRange& wr, const bool
                     if (prefix >= have) q = 0xffffffffu;
                     wr.next = wr.end = 0u;
                 } else {
-                    if (prefix >= have) q = base + (prefix - have);
+                    const uint32_t bi = (uint32_t)__builtin_amdgcn_readfirstlane((int)decode_range(base, n_chunks, tiles_x, world, HJR_COLD(rank), tile_order)); // (wave-uniform)
+                    if (prefix >= have) { q = base + (prefix - have); r_item = bi; }
                     wr.next = base + (n - have);
                     wr.end = base + 64u;
+                    wr.base_item = bi;
                 }
             } else wr.next += n;
             }
             // measured cost of a tile (orders the tiles of the next frame, hjr_cost_hist_kernel): a lane sums the rays of its
             // consecutive items of one tile and flushes when it moves on; lanes leaving the same tile together (the usual
             // case) share one atomic.  All lanes are here (m is wave-uniform), so the shuffles below are well defined.
-            const uint32_t old_tile = hjr_tile_id(HJR_PX(c) / HJR_TILE, HJR_PY(c) / HJR_TILE, tiles_x);
-            uint32_t new_tile = 0xffffffffu;
-            if (need && q < n_owned_items) new_tile = tile_order ? tile_order[(q >> 6) / n_chunks] : ((q >> 6) / n_chunks) * world + HJR_COLD(rank);
-            bool flush = need && tile_cost && c.it_cost != 0u && new_tile != old_tile;
-            while (__ballot(flush)) {
-                const int leader = __ffsll((long long)__ballot(flush)) - 1;
-                const uint32_t t = (uint32_t)__shfl((int)old_tile, leader);
-                const bool mine = flush && old_tile == t;
-                uint32_t v = mine ? c.it_cost : 0u;
-                for (int off = 32; off > 0; off >>= 1) v += (uint32_t)__shfl_xor((int)v, off);
-                if ((int)lane == leader) atomicAdd(&tile_cost[t / world], v);
-                if (mine) { c.it_cost = 0u; flush = false; }
+            if (wr.shared && need && q < n_owned_items) r_item = decode_range(q & ~63u, n_chunks, tiles_x, world, HJR_COLD(rank), tile_order); // (wavefront kernel: runs of the shared range, decoded per lane)
+            if (tile_cost) {
+                const uint32_t old_tile = hjr_tile_id(HJR_PX(c) / HJR_TILE, HJR_PY(c) / HJR_TILE, tiles_x);
+                const uint32_t new_tile = (need && q < n_owned_items) ? hjr_tile_id((r_item & 0x1fffu) / HJR_TILE, ((r_item >> 13) & 0x1fffu) / HJR_TILE, tiles_x) : 0xffffffffu;
+                bool flush = need && c.it_cost != 0u && new_tile != old_tile;
+                while (__ballot(flush)) {
+                    const int leader = __ffsll((long long)__ballot(flush)) - 1;
+                    const uint32_t t = (uint32_t)__shfl((int)old_tile, leader);
+                    const bool mine = flush && old_tile == t;
+                    uint32_t v = mine ? c.it_cost : 0u;
+                    for (int off = 32; off > 0; off >>= 1) v += (uint32_t)__shfl_xor((int)v, off);
+                    if ((int)lane == leader) atomicAdd(&tile_cost[t / world], v);
+                    if (mine) { c.it_cost = 0u; flush = false; }
+                }
             }
             if (need) {
                 if (q < n_owned_items) {
-                    // item q = ((owned tile * n_chunks) + chunk) * 64 + pixel-in-tile: the 64 lanes of a wave start on one
-                    // tile and one sample chunk (coherent primary rays)
-                    const uint32_t tc = q >> 6;
-                    const uint32_t tile = new_tile;
-                    const uint32_t chunk = tc % n_chunks;
-                    uint32_t tx, ty;
-                    hjr_tile_xy(tile, tiles_x, &tx, &ty);
-                    const uint32_t px = tx * HJR_TILE + (q & 7u);
-                    const uint32_t py = ty * HJR_TILE + ((q >> 3) & 7u);
+                    // the 64 lanes of a wave start on one tile and one sample chunk (coherent primary rays): the range's item word + the pixel in the tile
+                    const uint32_t item = r_item | (q & 7u) | (((q >> 3) & 7u) << 13);
+                    const uint32_t px = item & 0x1fffu, py = (item >> 13) & 0x1fffu, chunk = item >> 26;
                     if (px < P.width && py < P.height) {
                         c.has_item = true; c.path_live = false;
-                        c.item = px | (py << 13) | (chunk << 26);
+                        c.item = item;
                         c.s = chunk * P.chunk_spp;
                         c.sumL = V1(0.0f);
                         if (AOVS && c.aov) c.aov[0] = c.aov[1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -700,7 +717,7 @@ __global__ void __launch_bounds__(BLOCK, (LDSBVH ? 1 : HJR_MIN_WAVES)) hjr_rende
 
     LaneCtx c;
     ctx_reset(c);
-    WaveRange wr; wr.next = wr.end = 0u; wr.exhausted = false; wr.shared = nullptr;
+    WaveRange wr; wr.next = wr.end = 0u; wr.exhausted = false; wr.shared = nullptr; wr.base_item = 0u;
     bool inflight = false;      // carry-over: this lane's traversal continues in the next round (it skips everything else)
     bool tracing = false, occluded = false;
     Hit h;

@@ -480,7 +480,7 @@ __global__ void __launch_bounds__(BLOCK, 1) hjr_wavefront_kernel(const KParams P
 
     unsigned long long lc[HJR_NSTAT];
     if (STATS) for (int i = 0; i < HJR_NSTAT; i++) lc[i] = 0;
-    WaveRange wr; wr.next = wr.end = 0u; wr.exhausted = false; wr.shared = &Q->items;
+    WaveRange wr; wr.next = wr.end = 0u; wr.exhausted = false; wr.shared = &Q->items; wr.base_item = 0u;
 #ifdef HJR_WF_TIMING
     unsigned long long tdiag[19] = { 0 };
 #else

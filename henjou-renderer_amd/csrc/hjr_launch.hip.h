@@ -167,7 +167,7 @@ template <int I, bool S> static int launch_wf(hjr_ctx* c, const KParams& kp, uin
 }
 // descent loops of the fused traversals (hjr_traverse.hip.h): lanes still descending below which a pass moves on to the leaves
 #ifndef HJR_NODE_MIN_LDS
-#define HJR_NODE_MIN_LDS 4     /* megakernel, LDS-resident scenes (with AOVs, 1 / 4 / 8 / 12 / 16: 139.8 / 128.9 / 129.8 / 135.2 / 140.4 ms) */
+#define HJR_NODE_MIN_LDS 6     /* megakernel, LDS-resident scenes (round 2, with AOVs, 1 / 4 / 8 / 12 / 16: 139.8 / 128.9 / 129.8 / 135.2 / 140.4 ms; round 3 with a carry-over of 14 lanes, 4 / 5 / 6 / 7 / 8: 110.1 / 109.6 / 109.15 / 109.05 / 109.3) */
 #endif
 #ifndef HJR_NODE_MIN_LDS_WF
 #define HJR_NODE_MIN_LDS_WF 8  /* wavefront kernel, LDS-resident scenes (1 / 4 / 8 / 12 / 16: 132.4 / 125.4 / 124.8 / 125.7 / 126.4 ms) */

@@ -297,10 +297,13 @@ HD bool traverse(const float4* nodes, const float4* tris, f3 o, f3 d, float tmin
 // lane of this round has finished).  Those lanes keep their traversal state (TravCarry + hit + their LDS stack column),
 // skip the shading that follows and resume in the next round next to the other lanes' new rays: the wave's trip count per
 // round is set by the (64 - CARRY)-th slowest lane instead of the slowest one.  Per-lane results do not change.  The
-// threshold trades traversal lane-occupancy against shading lane-occupancy (profiles/r01_experiments.md): 8 for the
-// LDS-resident scenes (shading-heavy), 32 when nodes come from memory (traversal-heavy).
+// threshold trades traversal lane-occupancy against shading lane-occupancy (profiles/r01_experiments.md): 14 for the
+// LDS-resident scenes (8 in rounds 1 - 2; with the shading code of round 3 — shorter by its zero-weighted terms — 8 / 10 / 12 / 14 /
+// 16 / 18 / 20 lanes give 111.35 / 110.5 / 110.05 / 110.0 / 110.25 / 110.65 / 111.4 ms on the headline launch with node_min 4, and 14 lanes
+// with node_min 6 - 7 109.1), 32 when nodes come
+// from memory (traversal-heavy).
 #ifndef HJR_CARRY_LDS
-#define HJR_CARRY_LDS 8
+#define HJR_CARRY_LDS 14
 #endif
 #ifndef HJR_CARRY_MEM
 #define HJR_CARRY_MEM 32

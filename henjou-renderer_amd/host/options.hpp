@@ -22,7 +22,7 @@ inline const OptDesc* opt_table()
         { "lds_stack16", 0, 1 },     // 1 prefer 16-bit LDS stack entries whenever the tree admits them (default: only when 32-bit ones do not fit) [next hjr_set_transforms]
         { "bvh_width", 2, 4 },       // 2 / 4: force the node format (4 also forces the memory path); 3 is rejected                       [next hjr_set_transforms]
         { "leaf_max", 1, 4 },        // triangles per BVH leaf (default 2)                                                              [next hjr_set_transforms]
-        { "node_min", 1, 64 },       // descent loops: lanes still descending below which a pass moves on to the leaves (default 4 / 8 / 24 by layout and kernel family)
+        { "node_min", 1, 64 },       // descent loops: lanes still descending below which a pass moves on to the leaves (default 6 / 8 / 24 by layout and kernel family)
         { "hold_min", 0, 64 },       // megakernel, LDS layouts: metallic hits a wave collects before it shades them (0 never holds; default 8)
         { "hold_age", 1, 1000 },     // ... or rounds the oldest of them has waited (default 2)
         { "short_stack", 1, 64 },    // memory layouts: traversal-stack entries per lane kept in LDS (default 16; deeper ones overflow to HBM)

@@ -282,7 +282,7 @@ int hjr_get_stats(hjr_ctx*, hjr_stats* out);
  *   "bvh_width"       2 4         force the node format; 4 also forces the memory path (default: BVH2 in LDS when it fits, BVH4 otherwise)   [*]
  *   "leaf_max"        1..4        triangles per BVH leaf (2)                                                                        [*]
  *   "bvh_refine"      0..16       insertion-based refinement passes over the built BVH2, largest subtrees first (0 up to 65536 triangles, 1 above) [*]
- *   "node_min"        1..64       traversal descent loops: lanes still descending below which a pass moves on to the leaves (4 / 8 / 24 by layout and family)
+ *   "node_min"        1..64       traversal descent loops: lanes still descending below which a pass moves on to the leaves (6 / 8 / 24 by layout and family)
  *   "hold_min"        0..64       megakernel, LDS layouts: metallic hits a wave collects before it shades them; 0 never holds (8)
  *   "hold_age"        1..1000     ... or rounds the oldest of them has waited (2)
  *   "short_stack"     1..64       memory layouts: traversal-stack entries per lane kept in LDS, deeper ones overflow to HBM (16)

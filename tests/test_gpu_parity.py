@@ -147,6 +147,30 @@ def test_tile_order_is_pure_scheduling(cornell, dev):
         assert_bitexact(first[mask], ref[mask], "share %d vs full frame" % r)
 
 
+def test_plain_tile_order_shards_are_exact(cornell):
+    """Option tile_order = 0 (no tile list: owned tile k of rank r is tile k * R + r): the item decode of the ray-queue refill takes its other
+    branch; every share still equals the full frame on its tiles, at a ragged size with several sample chunks per pixel."""
+    from scene_util import device_options
+    w, h, spp, R = 200, 120, 35, 3
+    with device_options(tile_order=0):
+        d = cornell.device()
+        try:
+            full, _, _ = d.render(cornell.hjr_params(w, h, spp), want_aovs=False)
+            for r in range(R):
+                part, _, _ = d.render(cornell.hjr_params(w, h, spp, rank=r, world_size=R), want_aovs=False)
+                mask = hjr.owned_tile_mask(w, h, r, R)
+                assert_bitexact(part[mask], full[mask], "share %d" % r)
+        finally:
+            d.close()
+    with device_options():
+        d = cornell.device()
+        try:
+            ordered, _, _ = d.render(cornell.hjr_params(w, h, spp), want_aovs=False)
+        finally:
+            d.close()
+    assert_bitexact(full, ordered, "plain order vs class order")
+
+
 def test_ragged_sizes(cornell, dev, oracle):
     for (w, h) in [(1, 1), (7, 5), (9, 17)]:
         c, _, _ = dev.render(cornell.hjr_params(w, h, 2))

@@ -72,6 +72,17 @@ int main(int argc, char** argv)
         CHECK(fd.n_tris == v.n_triangles && fd.n_nodes > 0 && fd.stack_need >= 2);
         CHECK(fd.width == (allow_lds ? 2u : 4u));
     }
+    { // the insertion-based refinement (host/frame.cpp::Refine): same triangle set, a different tree, under the sanitizers
+        hjr::FrameData plain, refined;
+        hjr::BuildOptions bo;
+        bo.refine = 0;
+        CHECK(hjr::build_frame(copy, m.data(), inv.data(), ninst, bo, plain, err));
+        bo.refine = 4;
+        CHECK(hjr::build_frame(copy, m.data(), inv.data(), ninst, bo, refined, err));
+        CHECK(refined.n_tris == plain.n_tris && refined.n_nodes == plain.n_nodes && refined.tri_geom == plain.tri_geom); // leaves (triangle order) untouched
+        CHECK(refined.stack_need >= 2 && refined.depth < 32);
+        CHECK(refined.nodes != plain.nodes); // (the bundled scenes do move subtrees)
+    }
 
     // oracle render of a small frame through the same arrays
     std::vector<hjo_material> om(sc.materials.size());

@@ -213,15 +213,28 @@ HD f3 disney_eval(const KParams& P, const Disney& d, f3 wo, f3 wi) // :179-235
     // m_subsurface is forced to 0 (:170): lerp(f_diffuse, f_subsurface, 0) = f_diffuse + (f_subsurface - f_diffuse) * 0
     return (lerp3(f_diffuse, f_subsurface, 0.0f) + f_sheen) * (1.0f - d.metallic) + f_specular + f_clearcoat * d.clearcoat;
 }
-HD f3 disney_sample(const KParams& P, const Disney& d, f3 wo, f3& wi, float& pdf, CMJState& st) // :237-307
+// Lobe weights of sample() / getPDF() (:238-246, :310-316): three divisions by 1.5 - metallic.  A wave whose lanes all have metallic = 0 (every
+// non-metal of a glTF scene; metals above 0.5 take the multiple-scattering GGX lobe) uses the quotients of the constants: 1.0f * (1.0f - 0.0f) = 1,
+// (1 + 0.5) + 0 = 1.5, and 1 / 1.5, 0.5 / 1.5, 0 / 1.5 rounded as the correctly rounded division rounds them.
+HD void disney_weights(const Disney& d, float& dw, float& sw, float& cw)
 {
+    if (__ballot(d.metallic != 0.0f) == 0ull) {
+        constexpr float k_dw = 1.0f / 1.5f, k_sw = 0.5f / 1.5f, k_cw = 0.0f / 1.5f;
+        dw = k_dw; sw = k_sw; cw = k_cw;
+        return;
+    }
     float diffuseWeight = 1.0f * (1.0f - d.metallic);
     float specularWeight = 0.5f;
     float clearcoatWeight = 0.0f;
     float sumWeight = diffuseWeight + specularWeight + clearcoatWeight;
-    float dw = diffuseWeight / sumWeight;
-    float sw = specularWeight / sumWeight;
-    float cw = clearcoatWeight / sumWeight;
+    dw = diffuseWeight / sumWeight;
+    sw = specularWeight / sumWeight;
+    cw = clearcoatWeight / sumWeight;
+}
+HD f3 disney_sample(const KParams& P, const Disney& d, f3 wo, f3& wi, float& pdf, CMJState& st) // :237-307
+{
+    float dw, sw, cw;
+    disney_weights(d, dw, sw, cw);
     float select_p = cmj_1d(st);
     float pdf_diffuse = 1.0f, pdf_specular = 1.0f, pdf_clearcoat = 1.0f;
     f2 xi = cmj_2d(st);
@@ -269,10 +282,8 @@ HD f3 disney_sample(const KParams& P, const Disney& d, f3 wo, f3& wi, float& pdf
 }
 HD float disney_pdf(const Disney& d, f3 wo, f3 wi) // :309-326
 {
-    float diffuseWeight = 1.0f * (1.0f - d.metallic);
-    float specularWeight = 0.5f, clearcoatWeight = 0.0f;
-    float sumWeight = diffuseWeight + specularWeight + clearcoatWeight;
-    float dw = diffuseWeight / sumWeight, sw = specularWeight / sumWeight;
+    float dw, sw, cw;
+    disney_weights(d, dw, sw, cw);
     f3 wm = normalize(wo + wi);
     return dw * d_getPDFDiffuse(wi) + sw * d_getPDFSpecular(d.alpha, wm, wo, d.lambda_wo);
 }
